@@ -1,0 +1,16 @@
+"""esc_gnn_amd — MI355X-native hot path of ESC-GNN's NestedGIN_eff.
+
+Public surface mirrors the reference's modules for this path:
+    create_subgraphs (utils_edge_efficient.py), Batch (batch.py), DataLoader (dataloader.py),
+    NestedGIN_eff (run_graphcount.py), GINEConv.
+"""
+from .data import Data  # noqa: F401
+from .batch import Batch  # noqa: F401
+from .dataloader import DataLoader  # noqa: F401
+from .plan import BatchPlan, plan_of  # noqa: F401
+from . import _native, ops, optim  # noqa: F401
+from .nn import GINEConv, Linear, global_add_pool, global_mean_pool  # noqa: F401
+from .run_graphcount import NestedGIN_eff  # noqa: F401
+
+__all__ = ["Data", "Batch", "DataLoader", "BatchPlan", "plan_of", "GINEConv", "Linear",
+           "NestedGIN_eff", "global_add_pool", "global_mean_pool", "ops"]

@@ -1,0 +1,106 @@
+"""ctypes binding of libescgnn_hip.so (C ABI declared in include/escgnn_hip.h).
+
+The library is the product: there is NO fallback.  If the shared object is missing or a symbol
+cannot be resolved, importing/using the hot path raises immediately.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libescgnn_hip.so")
+ABI_VERSION = 1
+
+P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
+
+# name -> argtypes (every function returns int unless listed in _RET)
+SIGNATURES = {
+    "esc_abi_version": [],
+    "esc_last_error": [],
+    "esc_prof_enable": [I32, I32],
+    "esc_prof_read": [I32, POINTER(c_int64), POINTER(c_double)],
+    "esc_prof_reset": [I32],
+    "esc_bag_fwd": [P, I64, P, P, P, I64, P, I64, P],
+    "esc_bag_bwd_scratch": [I64, I64],
+    "esc_bag_bwd_table": [P, I64, I64, P, P, P, P, I64, I64, P, P, P],
+    "esc_gine_aggregate_fwd": [P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P],
+    "esc_gine_aggregate_bwd": [P, I64, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, P, P],
+    "esc_reduce_sum": [P, I64, P, P],
+    "esc_linear_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
+    "esc_linear_bwd_input": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
+    "esc_linear_bwd_weight_scratch": [I64, I64, I64],
+    "esc_linear_bwd_weight": [P, I64, P, I64, P, P, I64, I64, I64, P, I64, P, P, P],
+    "esc_bn_scratch": [I64],
+    "esc_bn_stats": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P],
+    "esc_bn_apply": [P, I64, I64, I64, P, P, P, P, I32, P, I64, P],
+    "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, I32, P, I64, P, P, P, P],
+    "esc_l1_loss": [P, P, I64, I64, F32, P, P, P],
+    "esc_adam_step": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P],
+}
+_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64,
+        "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64}
+
+KIND = {"agg_fwd": 0, "agg_bwd": 1, "bag_fwd": 2, "bag_bwd": 3, "linear": 4, "collate": 5,
+        "features": 6, "norm": 7}
+
+_lib = None
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "esc_gnn_amd: %s not found. The HIP hot path has no fallback — build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C esc-gnn_amd/csrc`." % LIB_PATH)
+    h = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as exc:
+            raise NativeLibraryError("esc_gnn_amd: %s lacks symbol %s (stale build?)" % (LIB_PATH, name)) from exc
+        fn.argtypes = args
+        fn.restype = _RET.get(name, c_int)
+    if h.esc_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("esc_gnn_amd: ABI version mismatch (lib %d, python %d) — rebuild"
+                                 % (h.esc_abi_version(), ABI_VERSION))
+    _lib = h
+    return h
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError with the library's message on failure."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, h.esc_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def prof_enable(kind, on=True):
+    call("esc_prof_enable", KIND[kind], int(on))
+
+
+def prof_reset(kind):
+    call("esc_prof_reset", KIND[kind])
+
+
+def prof_read(kind):
+    n, ms = c_int64(0), c_double(0.0)
+    call("esc_prof_read", KIND[kind], ctypes.byref(n), ctypes.byref(ms))
+    return n.value, ms.value

@@ -1,0 +1,270 @@
+// aggregate.hip — GINE neighbour aggregation (the "scatter-add" of NestedGIN_eff) without atomics.
+//
+//   forward   out[i,:] = (1+eps)*x[i,:] + sum_{k : dst_k = i, ascending k} relu(x[src_k,:] + e[k,:])
+//   backward  d_e[k,:] = [x[src_k,:]+e[k,:] > 0] * g[dst_k,:]
+//             dx[i,:]  = (1+eps)*g[i,:] + sum_{k : src_k = i} d_e[k,:]
+//             deps     = sum_{i,c} g[i,c]*x[i,c]
+//
+// Replaces PyG 2.0.4 GINEConv.propagate (index_select gather + torch_scatter scatter-add) reached
+// from /root/reference/run_graphcount.py:161,169; semantics as restated in
+// /root/reference/GraphGPS/graphgps/layer/gine_conv_layer.py:56-84 (minus r_ij); hand-rolled twin
+// /root/reference/ogb_mol_gnn.py:346-358.
+//
+// Design (HBM/L2-bound, no MFMA): global float atomics run at ~1.3 TB/s chip-wide on gfx950, so the
+// scatter is turned into a *segmented gather-reduce* over a destination-sorted CSR view of the
+// edge list (stable => the per-node sum runs in ascending edge order = the order a sequential
+// scatter_add_ uses => bitwise reproducible and bit-identical to the CPU oracle).  One wave owns
+// one node row; with C=256 each lane holds a float4, so every x/e row access is one coalesced
+// 1 KiB wave read.  x (N*C*4 = 2.4 MB @cfg1) stays L2-resident; e rows stream once.
+// Algorithmic bytes/launch: 2*E*C*4 + 2*N*C*4 + E*8 + (N+1)*4.
+#include "common.h"
+
+namespace esc {
+
+// ---- wide rows: one wave per node, VEC floats per lane per pass ---------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x, int64_t ld_x,
+                                                    const float* __restrict__ e, int64_t ld_e,
+                                                    const int* __restrict__ in_ptr,
+                                                    const int* __restrict__ in_edge,
+                                                    const int* __restrict__ in_src,
+                                                    const float* __restrict__ eps_p, int N, int C,
+                                                    float* __restrict__ out, int64_t ld_out) {
+  const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  if (node >= N) return;
+  const int lane = lane_id();
+  const int beg = uniform(in_ptr[node]);
+  const int end = uniform(in_ptr[node + 1]);
+  const float one_eps = __fadd_rn(1.0f, *eps_p);
+  for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+    int j = beg;
+    for (; j + 4 <= end; j += 4) {                 // 8 row reads in flight
+      float xv[4][VEC], ev[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = uniform(in_edge[j + u]);
+        const int s = uniform(in_src[j + u]);
+        const float* px = x + (size_t)s * ld_x + c;
+        const float* pe = e + (size_t)k * ld_e + c;
+        if constexpr (VEC == 4) {
+          const float4 a = *reinterpret_cast<const float4*>(px);
+          const float4 b = *reinterpret_cast<const float4*>(pe);
+          xv[u][0] = a.x; xv[u][1] = a.y; xv[u][2] = a.z; xv[u][3] = a.w;
+          ev[u][0] = b.x; ev[u][1] = b.y; ev[u][2] = b.z; ev[u][3] = b.w;
+        } else {
+          xv[u][0] = *px; ev[u][0] = *pe;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t)
+          acc[t] = __fadd_rn(acc[t], fmaxf(__fadd_rn(xv[u][t], ev[u][t]), 0.f));
+    }
+    for (; j < end; ++j) {
+      const int k = uniform(in_edge[j]);
+      const int s = uniform(in_src[j]);
+      const float* px = x + (size_t)s * ld_x + c;
+      const float* pe = e + (size_t)k * ld_e + c;
+      if constexpr (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(px);
+        const float4 b = *reinterpret_cast<const float4*>(pe);
+        acc[0] = __fadd_rn(acc[0], fmaxf(__fadd_rn(a.x, b.x), 0.f));
+        acc[1] = __fadd_rn(acc[1], fmaxf(__fadd_rn(a.y, b.y), 0.f));
+        acc[2] = __fadd_rn(acc[2], fmaxf(__fadd_rn(a.z, b.z), 0.f));
+        acc[3] = __fadd_rn(acc[3], fmaxf(__fadd_rn(a.w, b.w), 0.f));
+      } else {
+        acc[0] = __fadd_rn(acc[0], fmaxf(__fadd_rn(*px, *pe), 0.f));
+      }
+    }
+    const float* ps = x + (size_t)node * ld_x + c;
+    float* po = out + (size_t)node * ld_out + c;
+    if constexpr (VEC == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(ps);
+      *reinterpret_cast<float4*>(po) =
+          make_float4(__fadd_rn(acc[0], __fmul_rn(one_eps, a.x)), __fadd_rn(acc[1], __fmul_rn(one_eps, a.y)),
+                      __fadd_rn(acc[2], __fmul_rn(one_eps, a.z)), __fadd_rn(acc[3], __fmul_rn(one_eps, a.w)));
+    } else {
+      *po = __fadd_rn(acc[0], __fmul_rn(one_eps, *ps));
+    }
+  }
+}
+
+// ---- narrow rows (C < 64, e.g. the 10-wide first layer): one thread per (node, channel) ----------
+__global__ __launch_bounds__(256) void agg_fwd_elem(const float* __restrict__ x, int64_t ld_x,
+                                                    const float* __restrict__ e, int64_t ld_e,
+                                                    const int* __restrict__ in_ptr,
+                                                    const int* __restrict__ in_edge,
+                                                    const int* __restrict__ in_src,
+                                                    const float* __restrict__ eps_p, int N, int C,
+                                                    float* __restrict__ out, int64_t ld_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)N * C) return;
+  const int node = (int)(t / C), c = (int)(t % C);
+  const float one_eps = __fadd_rn(1.0f, *eps_p);
+  float acc = 0.f;
+  for (int j = in_ptr[node]; j < in_ptr[node + 1]; ++j) {
+    const float v = __fadd_rn(x[(size_t)in_src[j] * ld_x + c], e[(size_t)in_edge[j] * ld_e + c]);
+    acc = __fadd_rn(acc, fmaxf(v, 0.f));
+  }
+  out[(size_t)node * ld_out + c] = __fadd_rn(acc, __fmul_rn(one_eps, x[(size_t)node * ld_x + c]));
+}
+
+// ---- backward: one wave per SOURCE node (out-CSR) -------------------------------------------------
+// each edge has exactly one source, so d_e[k] is written exactly once and dx[i] needs no atomics.
+template <int VEC>
+__global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x, int64_t ld_x,
+                                                    const float* __restrict__ e, int64_t ld_e,
+                                                    const float* __restrict__ g, int64_t ld_g,
+                                                    const int* __restrict__ out_ptr,
+                                                    const int* __restrict__ out_edge,
+                                                    const int* __restrict__ out_dst,
+                                                    const float* __restrict__ eps_p, int N, int C,
+                                                    float* __restrict__ d_e, int64_t ld_de,
+                                                    float* __restrict__ dx, int64_t ld_dx,
+                                                    float* __restrict__ deps_part) {
+  const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  if (node >= N) return;
+  const int lane = lane_id();
+  const int beg = uniform(out_ptr[node]);
+  const int end = uniform(out_ptr[node + 1]);
+  const float one_eps = 1.0f + *eps_p;
+  float dot = 0.f;
+  for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+    float xi[VEC], gi[VEC], acc[VEC];
+    {
+      const float* px = x + (size_t)node * ld_x + c;
+      const float* pg = g + (size_t)node * ld_g + c;
+      if constexpr (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(px);
+        const float4 b = *reinterpret_cast<const float4*>(pg);
+        xi[0] = a.x; xi[1] = a.y; xi[2] = a.z; xi[3] = a.w;
+        gi[0] = b.x; gi[1] = b.y; gi[2] = b.z; gi[3] = b.w;
+      } else {
+        xi[0] = *px; gi[0] = *pg;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) { acc[t] = 0.f; dot = fmaf(xi[t], gi[t], dot); }
+#pragma unroll 4
+    for (int j = beg; j < end; ++j) {
+      const int k = uniform(out_edge[j]);
+      const int d = uniform(out_dst[j]);
+      const float* pe = e + (size_t)k * ld_e + c;
+      const float* pg = g + (size_t)d * ld_g + c;
+      float* pd = d_e + (size_t)k * ld_de + c;
+      if constexpr (VEC == 4) {
+        const float4 ev = *reinterpret_cast<const float4*>(pe);
+        const float4 gv = *reinterpret_cast<const float4*>(pg);
+        float4 o;
+        o.x = (__fadd_rn(xi[0], ev.x) > 0.f) ? gv.x : 0.f;
+        o.y = (__fadd_rn(xi[1], ev.y) > 0.f) ? gv.y : 0.f;
+        o.z = (__fadd_rn(xi[2], ev.z) > 0.f) ? gv.z : 0.f;
+        o.w = (__fadd_rn(xi[3], ev.w) > 0.f) ? gv.w : 0.f;
+        *reinterpret_cast<float4*>(pd) = o;
+        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+      } else {
+        const float o = (__fadd_rn(xi[0], *pe) > 0.f) ? *pg : 0.f;
+        *pd = o;
+        acc[0] += o;
+      }
+    }
+    if (dx != nullptr) {
+      float* po = dx + (size_t)node * ld_dx + c;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(po) = make_float4(fmaf(one_eps, gi[0], acc[0]), fmaf(one_eps, gi[1], acc[1]),
+                                                     fmaf(one_eps, gi[2], acc[2]), fmaf(one_eps, gi[3], acc[3]));
+      } else {
+        *po = fmaf(one_eps, gi[0], acc[0]);
+      }
+    }
+  }
+  if (deps_part != nullptr) {
+    dot = wave_sum(dot);
+    if (lane == 0) deps_part[node] = dot;
+  }
+}
+
+// deterministic single-block sum of n floats -> out[0] (fp64 accumulation)
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ v, int64_t n,
+                                                          float* __restrict__ out) {
+  __shared__ double sh[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double)v[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    out[0] = (float)t;
+  }
+}
+
+}  // namespace esc
+
+extern "C" {
+
+int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t ld_e,
+                           const int32_t* in_ptr, const int32_t* in_edge, const int32_t* in_src,
+                           const float* eps, int64_t N, int64_t C, float* out, int64_t ld_out,
+                           void* stream) {
+  ESC_REQUIRE(x && in_ptr && eps && out, "esc_gine_aggregate_fwd: null pointer");
+  ESC_REQUIRE(N >= 0 && C > 0 && ld_x >= C && ld_e >= C && ld_out >= C, "esc_gine_aggregate_fwd: bad sizes N=%ld C=%ld", (long)N, (long)C);
+  ESC_REQUIRE(N < (1LL << 31) / 64, "esc_gine_aggregate_fwd: N too large");
+  if (N == 0) return ESC_OK;
+  ESC_REQUIRE(e && in_edge && in_src, "esc_gine_aggregate_fwd: null edge arrays");
+  hipStream_t s = (hipStream_t)stream;
+  esc::ProfScope prof(ESC_K_AGG_FWD, s);
+  if (C >= 64) {
+    const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_e % 4 == 0) && (ld_out % 4 == 0) &&
+                     esc::aligned16(x) && esc::aligned16(e) && esc::aligned16(out);
+    const int64_t blocks = esc::cdiv(N, 4);
+    if (vec)
+      hipLaunchKernelGGL(esc::agg_fwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+    else
+      hipLaunchKernelGGL(esc::agg_fwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+  } else {
+    const int64_t blocks = esc::cdiv(N * C, 256);
+    hipLaunchKernelGGL(esc::agg_fwd_elem, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+  }
+  ESC_CHECK_LAUNCH("esc_gine_aggregate_fwd");
+  return ESC_OK;
+}
+
+int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t ld_e,
+                           const float* g, int64_t ld_g, const int32_t* out_ptr,
+                           const int32_t* out_edge, const int32_t* out_dst, const float* eps,
+                           int64_t N, int64_t C, float* d_e, int64_t ld_de, float* dx,
+                           int64_t ld_dx, float* deps_part, void* stream) {
+  ESC_REQUIRE(x && g && out_ptr && eps, "esc_gine_aggregate_bwd: null pointer");
+  ESC_REQUIRE(N >= 0 && C > 0 && ld_x >= C && ld_e >= C && ld_g >= C && ld_de >= C && (!dx || ld_dx >= C),
+              "esc_gine_aggregate_bwd: bad sizes");
+  ESC_REQUIRE(N < (1LL << 31) / 64, "esc_gine_aggregate_bwd: N too large");
+  if (N == 0) return ESC_OK;
+  ESC_REQUIRE(e && d_e && out_edge && out_dst, "esc_gine_aggregate_bwd: null edge arrays");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_e % 4 == 0) && (ld_g % 4 == 0) && (ld_de % 4 == 0) &&
+                   (!dx || ld_dx % 4 == 0) && esc::aligned16(x) && esc::aligned16(e) && esc::aligned16(g) &&
+                   esc::aligned16(d_e) && (!dx || esc::aligned16(dx));
+  const int64_t blocks = esc::cdiv(N, 4);
+  esc::ProfScope prof(ESC_K_AGG_BWD, s);
+  if (vec)
+    hipLaunchKernelGGL(esc::agg_bwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
+  else
+    hipLaunchKernelGGL(esc::agg_bwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
+  ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd");
+  return ESC_OK;
+}
+
+int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream) {
+  ESC_REQUIRE(out && (v || n == 0) && n >= 0, "esc_reduce_sum: bad argument");
+  hipLaunchKernelGGL(esc::reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out);
+  ESC_CHECK_LAUNCH("esc_reduce_sum");
+  return ESC_OK;
+}
+
+}  // extern "C"

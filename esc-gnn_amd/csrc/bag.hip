@@ -1,0 +1,235 @@
+// bag.hip — the ESC structural-encoding bag  z_emb = P * W  and its table gradient  dW = P^T * dZ.
+//
+// P is the batch's sparse E x 1800 integer count matrix (the per-edge ego-net histograms built by
+// create_subgraphs), W the 1800 x H embedding table (z_initial.weight).  Replaces
+//   global_add_pool(z_initial.weight[pos_index] * pos_enc.view(-1,1), pos_batch)
+// at /root/reference/run_graphcount.py:155 (= zinc_models.py:590, ogb_mol_gnn.py:716,
+// kernel/gin.py:342-344), which materialises a Z x H temporary (563 MB @cfg1) and scatter-adds it.
+//
+// Roofline: HBM-bound on paper (table 1.8 MB is L2-resident; algorithmic bytes = entries + output
+// rows); in practice bounded by L2->CU row traffic (Z rows of H floats).  One wave owns one output
+// row (an edge): the entry list of the row is wave-uniform, so indices/counts travel through the
+// scalar unit and every table row is one coalesced 16 B/lane read (H=256 => exactly 1 KiB/wave).
+#include "common.h"
+
+namespace esc {
+
+// ---- forward -----------------------------------------------------------------------------------
+// Bitwise contract: out = (((0 + w0*v0) + w1*v1) + ...) with separately rounded products, i.e.
+// what a sequential scatter_add_ of the rounded products gives.  __fmul_rn/__fadd_rn are never
+// contracted into an fma.
+template <int VEC>
+__global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ table, int H,
+                                                      const int* __restrict__ row_ptr,
+                                                      const int* __restrict__ idx,
+                                                      const int* __restrict__ val, int E,
+                                                      float* __restrict__ out, int64_t ld_out) {
+  const int row = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  if (row >= E) return;
+  const int lane = lane_id();
+  const int beg = uniform(row_ptr[row]);
+  const int end = uniform(row_ptr[row + 1]);
+  for (int c = lane * VEC; c < H; c += WAVE * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+    int j = beg;
+    // 4 table rows in flight per wave
+    for (; j + 4 <= end; j += 4) {
+      float w[4][VEC];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = uniform(idx[j + u]);
+        v[u] = (float)uniform(val[j + u]);
+        const float* p = table + (size_t)r * H + c;
+        if constexpr (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(p);
+          w[u][0] = q.x; w[u][1] = q.y; w[u][2] = q.z; w[u][3] = q.w;
+        } else {
+          w[u][0] = *p;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) acc[t] = __fadd_rn(acc[t], __fmul_rn(w[u][t], v[u]));
+    }
+    for (; j < end; ++j) {
+      const int r = uniform(idx[j]);
+      const float v = (float)uniform(val[j]);
+      const float* p = table + (size_t)r * H + c;
+      if constexpr (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        acc[0] = __fadd_rn(acc[0], __fmul_rn(q.x, v));
+        acc[1] = __fadd_rn(acc[1], __fmul_rn(q.y, v));
+        acc[2] = __fadd_rn(acc[2], __fmul_rn(q.z, v));
+        acc[3] = __fadd_rn(acc[3], __fmul_rn(q.w, v));
+      } else {
+        acc[0] = __fadd_rn(acc[0], __fmul_rn(*p, v));
+      }
+    }
+    float* o = out + (size_t)row * ld_out + c;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      *o = acc[0];
+    }
+  }
+}
+
+// ---- table gradient ----------------------------------------------------------------------------
+// CSC view (entries sorted by column, stable).  Pass 1: one wave per chunk of CH consecutive
+// sorted entries; a column that lies entirely inside the chunk is written straight to dtable,
+// a column that crosses a chunk border leaves a partial in slot[chunk][0] (segment touching the
+// chunk's first entry) or slot[chunk][1] (segment touching the last entry, if different).
+// Pass 2: one wave per column sums its partials in chunk order (=> bitwise reproducible) and
+// zero-fills columns without entries.
+constexpr int BAG_CH = 64;
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bag_bwd_pass1(const float* __restrict__ dz, int64_t ld_dz, int H,
+                                                     const int* __restrict__ col_ptr,
+                                                     const int* __restrict__ c_row,
+                                                     const int* __restrict__ c_val,
+                                                     const int* __restrict__ c_col, int Z,
+                                                     float* __restrict__ dtable,
+                                                     float* __restrict__ partials) {
+  const int chunk = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  const int beg = chunk * BAG_CH;
+  if (beg >= Z) return;
+  const int end = min(beg + BAG_CH, Z);
+  const int lane = lane_id();
+  for (int c0 = lane * VEC; c0 < H; c0 += WAVE * VEC) {
+    int j = beg;
+    while (j < end) {
+      const int col = uniform(c_col[j]);
+      const int cb = uniform(col_ptr[col]);
+      const int ce = uniform(col_ptr[col + 1]);
+      const int seg_end = min(ce, end);
+      float acc[VEC];
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+#pragma unroll 4
+      for (; j < seg_end; ++j) {
+        const int r = uniform(c_row[j]);
+        const float v = (float)uniform(c_val[j]);
+        const float* p = dz + (size_t)r * ld_dz + c0;
+        if constexpr (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(p);
+          acc[0] = fmaf(q.x, v, acc[0]); acc[1] = fmaf(q.y, v, acc[1]);
+          acc[2] = fmaf(q.z, v, acc[2]); acc[3] = fmaf(q.w, v, acc[3]);
+        } else {
+          acc[0] = fmaf(*p, v, acc[0]);
+        }
+      }
+      float* o;
+      if (cb >= beg && ce <= end) {
+        o = dtable + (size_t)col * H + c0;                      // column interior to this chunk
+      } else {
+        const int slot = (cb < beg) ? 0 : 1;                    // continues from previous chunk : runs into next
+        o = partials + ((size_t)chunk * 2 + slot) * H + c0;
+      }
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      } else {
+        *o = acc[0];
+      }
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bag_bwd_pass2(int H, const int* __restrict__ col_ptr, int n_cols,
+                                                     float* __restrict__ dtable,
+                                                     const float* __restrict__ partials) {
+  const int col = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  if (col >= n_cols) return;
+  const int cb = uniform(col_ptr[col]);
+  const int ce = uniform(col_ptr[col + 1]);
+  const int lane = lane_id();
+  const bool empty = ce == cb;
+  const int q0 = cb / BAG_CH;
+  const int q1 = empty ? q0 : (ce - 1) / BAG_CH;
+  const bool interior = !empty && q0 == q1;
+  // a column confined to one chunk was fully handled by pass 1 (it is "interior" there iff
+  // cb >= chunk begin and ce <= chunk end, which q0 == q1 implies)
+  if (interior) return;
+  for (int c0 = lane * VEC; c0 < H; c0 += WAVE * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+    if (!empty) {
+      for (int q = q0; q <= q1; ++q) {
+        const int slot = (cb < q * BAG_CH) ? 0 : 1;
+        const float* p = partials + ((size_t)q * 2 + slot) * H + c0;
+        if constexpr (VEC == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        } else {
+          acc[0] += *p;
+        }
+      }
+    }
+    float* o = dtable + (size_t)col * H + c0;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      *o = acc[0];
+    }
+  }
+}
+
+}  // namespace esc
+
+extern "C" {
+
+int esc_bag_fwd(const float* table, int64_t H, const int32_t* row_ptr, const int32_t* idx32,
+                const int32_t* val32, int64_t E, float* out, int64_t ld_out, void* stream) {
+  ESC_REQUIRE(table && row_ptr && out && idx32 && val32, "esc_bag_fwd: null pointer");
+  ESC_REQUIRE(H > 0 && E >= 0 && ld_out >= H, "esc_bag_fwd: bad sizes H=%ld E=%ld ld=%ld", (long)H, (long)E, (long)ld_out);
+  ESC_REQUIRE(E < (1LL << 31) / 64, "esc_bag_fwd: E too large");
+  if (E == 0) return ESC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (H % 4 == 0) && (ld_out % 4 == 0) && esc::aligned16(table) && esc::aligned16(out);
+  const int64_t blocks = esc::cdiv(E, 4);
+  esc::ProfScope prof(ESC_K_BAG_FWD, s);
+  if (vec)
+    hipLaunchKernelGGL(esc::bag_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
+  else
+    hipLaunchKernelGGL(esc::bag_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
+  ESC_CHECK_LAUNCH("esc_bag_fwd");
+  return ESC_OK;
+}
+
+int64_t esc_bag_bwd_scratch(int64_t Z, int64_t H) { return 2 * esc::cdiv(Z, esc::BAG_CH) * H; }
+
+int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
+                      const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
+                      int64_t n_cols, float* dtable, float* partials, void* stream) {
+  ESC_REQUIRE(dz && col_ptr && dtable, "esc_bag_bwd_table: null pointer");
+  ESC_REQUIRE(Z == 0 || (c_row && c_val && c_col && partials), "esc_bag_bwd_table: null entry arrays");
+  ESC_REQUIRE(H > 0 && Z >= 0 && n_cols > 0 && ld_dz >= H, "esc_bag_bwd_table: bad sizes");
+  ESC_REQUIRE(Z < (1LL << 31) - 64, "esc_bag_bwd_table: Z too large");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (H % 4 == 0) && (ld_dz % 4 == 0) && esc::aligned16(dz) && esc::aligned16(dtable) && esc::aligned16(partials);
+  esc::ProfScope prof(ESC_K_BAG_BWD, s);
+  if (Z > 0) {
+    const int64_t chunks = esc::cdiv(Z, esc::BAG_CH);
+    const int64_t blocks = esc::cdiv(chunks, 4);
+    if (vec)
+      hipLaunchKernelGGL(esc::bag_bwd_pass1<4>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
+    else
+      hipLaunchKernelGGL(esc::bag_bwd_pass1<1>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
+    ESC_CHECK_LAUNCH("esc_bag_bwd_table.pass1");
+  }
+  const int64_t blocks2 = esc::cdiv(n_cols, 4);
+  if (vec)
+    hipLaunchKernelGGL(esc::bag_bwd_pass2<4>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
+  else
+    hipLaunchKernelGGL(esc::bag_bwd_pass2<1>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
+  ESC_CHECK_LAUNCH("esc_bag_bwd_table.pass2");
+  return ESC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,412 @@
+// linear_mfma.hip — the dense layers of NestedGIN_eff on the gfx950 matrix cores in exact fp32.
+//
+//   forward      Y[M,N]  = act(X)[M,K] * W[N,K]^T + bias           (torch.nn.Linear)
+//   input grad   dX[M,K] = dY[M,N] * W[N,K]
+//   weight grad  dW[N,K] = dY[M,N]^T * act(X)[M,K],  db[N] = colsum(dY)
+//
+// Call sites replaced: every torch.nn.Linear of /root/reference/run_graphcount.py:54-121,183-189
+// and GINEConv.lin (edge_dim -> in_channels), the only GEMM-shaped work on the path.
+//
+// v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate) is a k-ordered fp32 fma chain — no TF32-like
+// truncation exists on gfx950 — so results stay within fp32 rounding of the CPU oracle (1e-5 bar).
+// Peak 157 TFLOP/s; these shapes (M = E or N_nodes, N,K <= 1280) are short-K, so the kernel is a
+// classic LDS-tiled, register-prefetched (global -> VGPR -> LDS, one barrier per 32-deep K step)
+// design with 4 waves per workgroup, each owning (BM/WM) x (BN/WN) of the tile as 32x32 MFMA blocks.
+//
+// Operand forms.  "k-contiguous": the reduction index is the fastest-moving index in memory
+// (X[M,K], W[N,K] in forward).  LDS image [row][BK+4]; a lane fetches 4 consecutive k of its row
+// with one ds_read_b128 (conflict-free with the +4 pad) and feeds 4 MFMAs — lane half h owns
+// k = 8c+4h+t, so the k order inside an 8-chunk is permuted identically for A and B.
+// "reduction-major": the reduction index is the row index in memory (W[N,K] for dX, dY and X for
+// dW).  LDS image [k][cols+4]; a lane reads single floats (ds_read_b32, consecutive lanes ->
+// consecutive banks).
+#include "common.h"
+#include <type_traits>
+
+namespace esc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int KPAD = 4;
+
+template <int ROWS>
+struct KContigTile {            // [ROWS][BK+KPAD]
+  static constexpr int LD = BK + KPAD;
+  static constexpr int FLOATS = ROWS * LD;
+  static constexpr int PER_THREAD = ROWS * (BK / 4) / 256;  // float4 per thread
+};
+template <int COLS>
+struct RedMajorTile {           // [BK][COLS+KPAD]
+  static constexpr int LD = COLS + KPAD;
+  static constexpr int FLOATS = BK * LD;
+  static constexpr int PER_THREAD = BK * (COLS / 4) / 256;
+};
+
+// ---- global -> register staging ------------------------------------------------------------------
+// k-contiguous: rows r0.. of `src` (ld), reduction range [k0, k0+BK); element (r, k) valid iff
+// r < rows && k < kdim.  Optional per-k affine+relu (fused BatchNorm+ReLU of the producer).
+template <int ROWS, bool PRO>
+__device__ __forceinline__ void load_kcontig(const float* __restrict__ src, int64_t ld, int r0, int rows,
+                                             int k0, int kdim, bool vec_ok,
+                                             const float* __restrict__ sc, const float* __restrict__ sh,
+                                             float4 (&reg)[KContigTile<ROWS>::PER_THREAD]) {
+  const int tid = threadIdx.x;
+  const int kq = tid & 7;
+  const int k = k0 + kq * 4;
+#pragma unroll
+  for (int p = 0; p < KContigTile<ROWS>::PER_THREAD; ++p) {
+    const int r = r0 + (tid >> 3) + p * 32;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      const float* q = src + (size_t)r * ld + k;
+      if (vec_ok && k + 3 < kdim) {
+        v = *reinterpret_cast<const float4*>(q);
+      } else {
+        if (k + 0 < kdim) v.x = q[0];
+        if (k + 1 < kdim) v.y = q[1];
+        if (k + 2 < kdim) v.z = q[2];
+        if (k + 3 < kdim) v.w = q[3];
+      }
+      if constexpr (PRO) {
+        if (k + 0 < kdim) v.x = fmaxf(fmaf(v.x, sc[k + 0], sh[k + 0]), 0.f);
+        if (k + 1 < kdim) v.y = fmaxf(fmaf(v.y, sc[k + 1], sh[k + 1]), 0.f);
+        if (k + 2 < kdim) v.z = fmaxf(fmaf(v.z, sc[k + 2], sh[k + 2]), 0.f);
+        if (k + 3 < kdim) v.w = fmaxf(fmaf(v.w, sc[k + 3], sh[k + 3]), 0.f);
+      }
+    }
+    reg[p] = v;
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_kcontig(float* __restrict__ lds, const float4 (&reg)[KContigTile<ROWS>::PER_THREAD]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < KContigTile<ROWS>::PER_THREAD; ++p) {
+    const int r = (tid >> 3) + p * 32;
+    *reinterpret_cast<float4*>(lds + r * KContigTile<ROWS>::LD + (tid & 7) * 4) = reg[p];
+  }
+}
+
+// reduction-major: rows (reduction) [k0, k0+BK) of `src`, columns c0..c0+COLS; valid iff k < kdim && c < cols.
+// Optional per-COLUMN affine+relu (for act(X) in the weight gradient).
+template <int COLS, bool PRO>
+__device__ __forceinline__ void load_redmajor(const float* __restrict__ src, int64_t ld, int k0, int kdim,
+                                              int c0, int cols, bool vec_ok,
+                                              const float* __restrict__ sc, const float* __restrict__ sh,
+                                              float4 (&reg)[RedMajorTile<COLS>::PER_THREAD]) {
+  const int tid = threadIdx.x;
+  constexpr int QPR = COLS / 4;  // float4 per row
+#pragma unroll
+  for (int p = 0; p < RedMajorTile<COLS>::PER_THREAD; ++p) {
+    const int f = tid + p * 256;
+    const int kk = f / QPR, cq = f % QPR;
+    const int k = k0 + kk, c = c0 + cq * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < kdim) {
+      const float* q = src + (size_t)k * ld + c;
+      if (vec_ok && c + 3 < cols) {
+        v = *reinterpret_cast<const float4*>(q);
+      } else {
+        if (c + 0 < cols) v.x = q[0];
+        if (c + 1 < cols) v.y = q[1];
+        if (c + 2 < cols) v.z = q[2];
+        if (c + 3 < cols) v.w = q[3];
+      }
+      if constexpr (PRO) {
+        if (c + 0 < cols) v.x = fmaxf(fmaf(v.x, sc[c + 0], sh[c + 0]), 0.f);
+        if (c + 1 < cols) v.y = fmaxf(fmaf(v.y, sc[c + 1], sh[c + 1]), 0.f);
+        if (c + 2 < cols) v.z = fmaxf(fmaf(v.z, sc[c + 2], sh[c + 2]), 0.f);
+        if (c + 3 < cols) v.w = fmaxf(fmaf(v.w, sc[c + 3], sh[c + 3]), 0.f);
+      }
+    }
+    reg[p] = v;
+  }
+}
+template <int COLS>
+__device__ __forceinline__ void store_redmajor(float* __restrict__ lds, const float4 (&reg)[RedMajorTile<COLS>::PER_THREAD]) {
+  const int tid = threadIdx.x;
+  constexpr int QPR = COLS / 4;
+#pragma unroll
+  for (int p = 0; p < RedMajorTile<COLS>::PER_THREAD; ++p) {
+    const int f = tid + p * 256;
+    *reinterpret_cast<float4*>(lds + (f / QPR) * RedMajorTile<COLS>::LD + (f % QPR) * 4) = reg[p];
+  }
+}
+
+// ---- fragment reads: 4 consecutive MFMA k-steps of one 32-row block -----------------------------
+// returns f[t] = operand value for MFMA t of 8-chunk `c8` (k = 8*c8 + 4*h + t)
+template <int ROWS>
+__device__ __forceinline__ float4 frag_kcontig(const float* __restrict__ lds, int row0, int c8) {
+  const int l = lane_id();
+  return *reinterpret_cast<const float4*>(lds + (row0 + (l & 31)) * KContigTile<ROWS>::LD + c8 * 8 + (l >> 5) * 4);
+}
+template <int COLS>
+__device__ __forceinline__ float4 frag_redmajor(const float* __restrict__ lds, int col0, int c8) {
+  const int l = lane_id();
+  const float* p = lds + (c8 * 8 + (l >> 5) * 4) * RedMajorTile<COLS>::LD + col0 + (l & 31);
+  return make_float4(p[0], p[RedMajorTile<COLS>::LD], p[2 * RedMajorTile<COLS>::LD], p[3 * RedMajorTile<COLS>::LD]);
+}
+
+// =================================================================================================
+// Generic tile kernel.  C[BM x BN] (+)= A_op[BM x R] * B_op[R x BN] over reduction range
+// [red0, red1) (blockIdx.z selects the split for the weight gradient).
+//   A_KC : A operand k-contiguous (rows = output rows)   else reduction-major (cols = output rows)
+//   B_KC : B operand k-contiguous (rows = output cols)   else reduction-major (cols = output cols)
+// =================================================================================================
+struct GemmArgs {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  const float* bias;        // per output column (forward) or nullptr
+  const float* pro_scale;   // prologue affine (applies to A if A_KC: per k; to B if !B_KC && !A_KC: per col)
+  const float* pro_shift;
+  float* db_part;           // weight grad: per-split column sums of A' (= dY)   [splits][rowsC]
+  int rowsC, colsC, red;    // output rows, output cols, reduction length
+  int red_per_split;
+  int accumulate;
+  int a_vec, b_vec, c_slab; // alignment flags; c_slab: C is a [splits][rowsC][colsC] slab buffer
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool PRO, bool DB>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  static_assert(MT >= 1 && NT >= 1, "wave tile must hold at least one 32x32 block");
+  using ATile = typename std::conditional<A_KC, KContigTile<BM>, RedMajorTile<BM>>::type;
+  using BTile = typename std::conditional<B_KC, KContigTile<BN>, RedMajorTile<BN>>::type;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (ATile::FLOATS + BTile::FLOATS)];
+  constexpr int STAGE = ATile::FLOATS + BTile::FLOATS;   // one K-step of A then B
+
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int split = blockIdx.z;
+  const int red0 = split * g.red_per_split;
+  const int red1 = min(g.red, red0 + g.red_per_split);
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l = lane_id();
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[ATile::PER_THREAD];
+  float4 rb[BTile::PER_THREAD];
+  float dbsum = 0.f;
+
+  auto gload = [&](int k0) {
+    if constexpr (A_KC) load_kcontig<BM, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
+    else                load_redmajor<BM, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
+    if constexpr (B_KC) load_kcontig<BN, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
+    else                load_redmajor<BN, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
+  };
+  auto lstore = [&](int buf) {
+    float* a_w = lds + buf * STAGE;
+    float* b_w = a_w + ATile::FLOATS;
+    if constexpr (A_KC) store_kcontig<BM>(a_w, ra); else store_redmajor<BM>(a_w, ra);
+    if constexpr (B_KC) store_kcontig<BN>(b_w, rb); else store_redmajor<BN>(b_w, rb);
+  };
+
+  const int nk = (red1 > red0) ? (red1 - red0 + BK - 1) / BK : 0;
+  if (nk > 0) {
+    gload(red0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(red0 + (kt + 1) * BK);
+    const float* a_l = lds + cur * STAGE;
+    const float* b_l = a_l + ATile::FLOATS;
+    if constexpr (DB) {   // column sums of the reduction-major A' tile (bias gradient), block column 0 only
+      if (blockIdx.x == 0 && threadIdx.x < BM) {
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) dbsum += a_l[kk * ATile::LD + threadIdx.x];
+      }
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < BK / 8; ++c8) {
+      float4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if constexpr (A_KC) af[i] = frag_kcontig<BM>(a_l, wm * TM + i * 32, c8);
+        else                af[i] = frag_redmajor<BM>(a_l, wm * TM + i * 32, c8);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (B_KC) bf[j] = frag_kcontig<BN>(b_l, wn * TN + j * 32, c8);
+        else                bf[j] = frag_redmajor<BN>(b_l, wn * TN + j * 32, c8);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cbase = g.C + (g.c_slab ? (size_t)split * g.rowsC * g.ldc : 0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * TN + j * 32 + (l & 31);
+      if (col >= g.colsC) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (row < g.rowsC) {
+          float* p = Cbase + (size_t)row * g.ldc + col;
+          float v = acc[i][j][r] + bv;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  if constexpr (DB) {
+    if (blockIdx.x == 0 && threadIdx.x < BM && m0 + (int)threadIdx.x < g.rowsC)
+      g.db_part[(size_t)split * g.rowsC + m0 + threadIdx.x] = dbsum;
+  }
+}
+
+// sum `splits` slabs of `n` floats in fixed order: out[i] = sum_s slab[s][i]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int splits,
+                                                          int cols, float* __restrict__ out, int64_t ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int q = 0; q < splits; ++q) s += slabs[(size_t)q * n + i];
+  out[(i / cols) * ld_out + (i % cols)] = s;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool PRO, bool DB>
+static void launch_tile(const GemmArgs& g, int splits, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(g.colsC, BN), (unsigned)cdiv(g.rowsC, BM), (unsigned)splits);
+  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, A_KC, B_KC, PRO, DB>), grid, dim3(256), 0, s, g);
+}
+
+static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (ld % 4 == 0); }
+
+}  // namespace esc
+
+using namespace esc;
+
+extern "C" {
+
+int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                   const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
+                   float* Y, int64_t ld_y, float* col_stats, void* stream) {
+  ESC_REQUIRE(X && W && Y, "esc_linear_fwd: null pointer");
+  ESC_REQUIRE(M >= 0 && N > 0 && K > 0 && ld_x >= K && ld_w >= K && ld_y >= N, "esc_linear_fwd: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_fwd: in_scale/in_shift must come together");
+  ESC_REQUIRE(col_stats == nullptr, "esc_linear_fwd: col_stats not supported in this ABI revision");
+  ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_fwd: dimension too large");
+  if (M == 0) return ESC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g{};
+  g.A = X; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.C = Y; g.ldc = ld_y; g.bias = bias;
+  g.pro_scale = in_scale; g.pro_shift = in_shift; g.db_part = nullptr;
+  g.rowsC = (int)M; g.colsC = (int)N; g.red = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
+  g.a_vec = vec_ok(X, ld_x); g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
+  ProfScope prof(ESC_K_LINEAR, s);
+  const bool pro = in_scale != nullptr;
+  if (N <= 32) {
+    if (pro) launch_tile<128, 32, 4, 1, true, true, true, false>(g, 1, s);
+    else     launch_tile<128, 32, 4, 1, true, true, false, false>(g, 1, s);
+  } else if (M >= 8192) {
+    if (pro) launch_tile<128, 128, 2, 2, true, true, true, false>(g, 1, s);
+    else     launch_tile<128, 128, 2, 2, true, true, false, false>(g, 1, s);
+  } else {
+    if (pro) launch_tile<64, 64, 2, 2, true, true, true, false>(g, 1, s);
+    else     launch_tile<64, 64, 2, 2, true, true, false, false>(g, 1, s);
+  }
+  ESC_CHECK_LAUNCH("esc_linear_fwd");
+  return ESC_OK;
+}
+
+int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
+                         int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate,
+                         void* stream) {
+  ESC_REQUIRE(dY && W && dX, "esc_linear_bwd_input: null pointer");
+  ESC_REQUIRE(M >= 0 && N > 0 && K > 0 && ld_dy >= N && ld_w >= K && ld_dx >= K, "esc_linear_bwd_input: bad sizes");
+  ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_input: dimension too large");
+  if (M == 0) return ESC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g{};
+  g.A = dY; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.C = dX; g.ldc = ld_dx; g.bias = nullptr;
+  g.rowsC = (int)M; g.colsC = (int)K; g.red = (int)N; g.red_per_split = (int)N; g.accumulate = accumulate;
+  g.a_vec = vec_ok(dY, ld_dy); g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
+  ProfScope prof(ESC_K_LINEAR, s);
+  if (K <= 32)        launch_tile<128, 32, 4, 1, true, false, false, false>(g, 1, s);
+  else if (M >= 8192) launch_tile<128, 128, 2, 2, true, false, false, false>(g, 1, s);
+  else                launch_tile<64, 64, 2, 2, true, false, false, false>(g, 1, s);
+  ESC_CHECK_LAUNCH("esc_linear_bwd_input");
+  return ESC_OK;
+}
+
+static void wgrad_plan(int64_t M, int64_t N, int64_t K, int* splits, int* per_split) {
+  // 64x64 output tiles; enough splits along M for >= ~512 workgroups, each >= 128 rows deep
+  const int64_t tiles = cdiv(N, 64) * cdiv(K, 64);
+  int64_t want = cdiv(512, tiles);
+  int64_t max_splits = cdiv(M, 128);
+  int64_t sp = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+  if (sp < 1) sp = 1;
+  int64_t per = cdiv(cdiv(M, sp), BK) * BK;
+  sp = cdiv(M, per);
+  if (sp < 1) sp = 1;
+  *splits = (int)sp;
+  *per_split = (int)per;
+}
+
+int64_t esc_linear_bwd_weight_scratch(int64_t M, int64_t N, int64_t K) {
+  int sp, per;
+  wgrad_plan(M, N, K, &sp, &per);
+  return (int64_t)sp * (N * K + N);
+}
+
+int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x,
+                          const float* in_scale, const float* in_shift, int64_t M, int64_t N,
+                          int64_t K, float* dW, int64_t ld_dw, float* db, float* slabs,
+                          void* stream) {
+  ESC_REQUIRE(dY && X && dW && slabs, "esc_linear_bwd_weight: null pointer");
+  ESC_REQUIRE(M > 0 && N > 0 && K > 0 && ld_dy >= N && ld_x >= K && ld_dw >= K, "esc_linear_bwd_weight: bad sizes");
+  ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_bwd_weight: in_scale/in_shift must come together");
+  ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_weight: dimension too large");
+  hipStream_t s = (hipStream_t)stream;
+  int sp, per;
+  wgrad_plan(M, N, K, &sp, &per);
+  GemmArgs g{};
+  g.A = dY; g.lda = ld_dy; g.B = X; g.ldb = ld_x; g.C = slabs; g.ldc = K; g.bias = nullptr;
+  g.pro_scale = in_scale; g.pro_shift = in_shift;
+  g.db_part = slabs + (size_t)sp * N * K;
+  g.rowsC = (int)N; g.colsC = (int)K; g.red = (int)M; g.red_per_split = per; g.accumulate = 0;
+  g.a_vec = vec_ok(dY, ld_dy); g.b_vec = vec_ok(X, ld_x); g.c_slab = 1;
+  ProfScope prof(ESC_K_LINEAR, s);
+  if (in_scale) launch_tile<64, 64, 2, 2, false, false, true, true>(g, sp, s);
+  else          launch_tile<64, 64, 2, 2, false, false, false, true>(g, sp, s);
+  ESC_CHECK_LAUNCH("esc_linear_bwd_weight.tiles");
+  const int64_t n = N * K;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, slabs, n, sp, (int)K, dW, ld_dw);
+  ESC_CHECK_LAUNCH("esc_linear_bwd_weight.reduce");
+  if (db) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, g.db_part, N, sp, (int)N, db, N);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_weight.bias");
+  }
+  return ESC_OK;
+}
+
+}  // extern "C"

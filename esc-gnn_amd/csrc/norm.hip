@@ -1,0 +1,251 @@
+// norm.hip — BatchNorm1d with batch statistics (+ fused ReLU) forward/backward for [rows, C] activations.
+//
+// Replaces torch.nn.BatchNorm1d(+ReLU) at /root/reference/run_graphcount.py:55-60 (z_embedding, over
+// all E edge rows of the batch), :66-72 (x_embedding), :80-87,:100-107 (GINEConv.nn), :115 (bn_lin1).
+// HBM-bound elementwise/reduction work: every pass reads whole 256 B..1 KiB row segments per wave
+// (lane = column), rows are strided over waves.  Statistics are accumulated per wave around a shift
+// (first row of the wave's stripe) and merged with Chan's formula in fp64, so fp32 cancellation in
+// E[x^2]-E[x]^2 never shows up at the 1e-5 parity bar.
+#include "common.h"
+
+namespace esc {
+
+constexpr int NORM_ROWBLOCKS = 64;          // grid.y; x4 waves => 256 row slots
+
+// slot p owns rows p, p+P, p+2P, ...   partial[(p*C + c)] = {mean, M2}
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ X, int64_t ld, int M, int C,
+                                                         float2* __restrict__ partial) {
+  const int c = blockIdx.x * 64 + lane_id();
+  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int P = gridDim.y * 4;
+  if (c >= C) return;
+  float shift = 0.f, s1 = 0.f, s2 = 0.f;
+  int n = 0;
+  if (slot < M) shift = X[(size_t)slot * ld + c];
+#pragma unroll 4
+  for (int r = slot; r < M; r += P) {
+    const float d = X[(size_t)r * ld + c] - shift;
+    s1 += d;
+    s2 = fmaf(d, d, s2);
+    ++n;
+  }
+  float2 out = make_float2(0.f, 0.f);
+  if (n > 0) {
+    const double m = (double)s1 / n;
+    out.x = (float)((double)shift + m);
+    out.y = (float)fmax((double)s2 - (double)s1 * m, 0.0);
+  }
+  partial[(size_t)slot * C + c] = out;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restrict__ partial, int M, int C, int P,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ invstd,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  for (int p = 0; p < P && p < M; ++p) {
+    const double np = (double)((M - p + P - 1) / P);       // rows owned by slot p
+    const float2 v = partial[(size_t)p * C + c];
+    const double delta = (double)v.x - mu;
+    const double tot = n + np;
+    mu += delta * np / tot;
+    m2 += (double)v.y + delta * delta * n * np / tot;
+    n = tot;
+  }
+  const double var = m2 / (double)M;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (double)(M - 1));
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int C,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu,
+                                                       float* __restrict__ Y, int64_t ldy) {
+  const int cv = C / VEC;
+  const int64_t total = M * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    float xv[VEC], yv[VEC];
+    if constexpr (VEC == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(X + r * ldx + c);
+      xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+    } else {
+      xv[0] = X[r * ldx + c];
+    }
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      float v = (xv[t] - mean[c + t]) * invstd[c + t];
+      v = fmaf(v, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f);
+      yv[t] = relu ? fmaxf(v, 0.f) : v;
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(Y + r * ldy + c) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+    } else {
+      Y[r * ldy + c] = yv[0];
+    }
+  }
+}
+
+// backward partials: slot sums of g and g*xhat, g = dY * [Y > 0] (relu) ; partial[(p*C+c)] = {s1, s2}
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ Y, int64_t ldy,
+                                                             const float* __restrict__ dY, int64_t ldg, int M,
+                                                             int C, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int relu,
+                                                             float2* __restrict__ partial) {
+  const int c = blockIdx.x * 64 + lane_id();
+  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int P = gridDim.y * 4;
+  if (c >= C) return;
+  const float mu = mean[c], is = invstd[c];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+  for (int r = slot; r < M; r += P) {
+    float g = dY[(size_t)r * ldg + c];
+    if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
+    const float xh = (X[(size_t)r * ldx + c] - mu) * is;
+    s1 += g;
+    s2 = fmaf(g, xh, s2);
+  }
+  partial[(size_t)slot * C + c] = make_float2(s1, s2);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ partial, int M, int C,
+                                                              int P, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta,
+                                                              float2* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = 0; p < P; ++p) {
+    const float2 v = partial[(size_t)p * C + c];
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  if (dgamma) dgamma[c] = (float)s2;
+  if (dbeta) dbeta[c] = (float)s1;
+  coef[c] = make_float2((float)(s1 / M), (float)(s2 / M));
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ X, int64_t ldx,
+                                                           const float* __restrict__ Y, int64_t ldy,
+                                                           const float* __restrict__ dY, int64_t ldg, int64_t M,
+                                                           int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, int relu,
+                                                           const float2* __restrict__ coef,
+                                                           float* __restrict__ dX, int64_t ldd) {
+  const int cv = C / VEC;
+  const int64_t total = M * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    float xv[VEC], yv[VEC], gv[VEC], ov[VEC];
+    if constexpr (VEC == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(X + r * ldx + c);
+      const float4 g = *reinterpret_cast<const float4*>(dY + r * ldg + c);
+      xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+      gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
+      if (relu) {
+        const float4 y = *reinterpret_cast<const float4*>(Y + r * ldy + c);
+        yv[0] = y.x; yv[1] = y.y; yv[2] = y.z; yv[3] = y.w;
+      }
+    } else {
+      xv[0] = X[r * ldx + c];
+      gv[0] = dY[r * ldg + c];
+      if (relu) yv[0] = Y[r * ldy + c];
+    }
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      const float g = (relu && !(yv[t] > 0.f)) ? 0.f : gv[t];
+      const float is = invstd[c + t];
+      const float xh = (xv[t] - mean[c + t]) * is;
+      const float2 k = coef[c + t];
+      ov[t] = (gamma ? gamma[c + t] : 1.f) * is * (g - k.x - xh * k.y);
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(dX + r * ldd + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    } else {
+      dX[r * ldd + c] = ov[0];
+    }
+  }
+}
+
+static inline int rowblocks(int64_t M) { return (int)(M < 4 * NORM_ROWBLOCKS ? cdiv(M, 4) : NORM_ROWBLOCKS); }
+
+}  // namespace esc
+
+using namespace esc;
+
+extern "C" {
+
+int64_t esc_bn_scratch(int64_t C) { return (int64_t)NORM_ROWBLOCKS * 4 * C * 2 + 2 * C; }
+
+int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, float momentum,
+                 float* mean, float* invstd, float* running_mean, float* running_var, float* scratch,
+                 void* stream) {
+  ESC_REQUIRE(X && mean && invstd && scratch, "esc_bn_stats: null pointer");
+  ESC_REQUIRE(M > 1 && C > 0 && ld_x >= C && M < (1LL << 31), "esc_bn_stats: need more than 1 row per channel (M=%ld, C=%ld)", (long)M, (long)C);
+  hipStream_t s = (hipStream_t)stream;
+  const int rb = rowblocks(M);
+  ProfScope prof(ESC_K_NORM, s);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
+  ESC_CHECK_LAUNCH("esc_bn_stats.partial");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, eps, momentum, mean, invstd, running_mean, running_var);
+  ESC_CHECK_LAUNCH("esc_bn_stats.finalize");
+  return ESC_OK;
+}
+
+int esc_bn_apply(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* mean,
+                 const float* invstd, const float* gamma, const float* beta, int relu, float* Y,
+                 int64_t ld_y, void* stream) {
+  ESC_REQUIRE(X && Y && mean && invstd, "esc_bn_apply: null pointer");
+  ESC_REQUIRE(M >= 0 && C > 0 && ld_x >= C && ld_y >= C, "esc_bn_apply: bad sizes");
+  if (M == 0) return ESC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && aligned16(X) && aligned16(Y);
+  const int64_t work = M * (vec ? C / 4 : C);
+  const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
+  ProfScope prof(ESC_K_NORM, s);
+  if (vec) hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, mean, invstd, gamma, beta, relu, Y, ld_y);
+  else     hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, mean, invstd, gamma, beta, relu, Y, ld_y);
+  ESC_CHECK_LAUNCH("esc_bn_apply");
+  return ESC_OK;
+}
+
+int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
+               int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
+               const float* gamma, int relu, float* dX, int64_t ld_dx, float* dgamma, float* dbeta,
+               float* scratch, void* stream) {
+  ESC_REQUIRE(X && dY && dX && mean && invstd && scratch && (!relu || Y), "esc_bn_bwd: null pointer");
+  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && (!relu || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int rb = rowblocks(M);
+  float2* partial = (float2*)scratch;
+  float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
+  ProfScope prof(ESC_K_NORM, s);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, partial);
+  ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
+  ESC_CHECK_LAUNCH("esc_bn_bwd.finalize");
+  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) && (!relu || ld_y % 4 == 0) &&
+                   aligned16(X) && aligned16(dY) && aligned16(dX) && (!relu || aligned16(Y));
+  const int64_t work = M * (vec ? C / 4 : C);
+  const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
+  if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
+  else     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
+  ESC_CHECK_LAUNCH("esc_bn_bwd.apply");
+  return ESC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// runtime.hip — error reporting + HIP-event kernel-family profiler of libescgnn_hip.so
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace esc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct ProfState {
+  bool on = false;
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+};
+static ProfState g_prof[ESC_K_COUNT];
+static std::mutex g_prof_mu;
+
+ProfScope::ProfScope(int k, hipStream_t s) : kind(k), stream(s), slot(-1) {
+  if (k < 0 || k >= ESC_K_COUNT || !g_prof[k].on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfState& p = g_prof[k];
+  if (p.used == p.start.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    p.start.push_back(a);
+    p.stop.push_back(b);
+  }
+  slot = (int)p.used++;
+  (void)hipEventRecord(p.start[slot], stream);
+}
+
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  (void)hipEventRecord(g_prof[kind].stop[slot], stream);
+}
+
+}  // namespace esc
+
+extern "C" {
+
+int esc_abi_version(void) { return 1; }
+const char* esc_last_error(void) { return esc::g_err; }
+
+int esc_prof_enable(int kind, int on) {
+  ESC_REQUIRE(kind >= 0 && kind < ESC_K_COUNT, "esc_prof_enable: bad kind %d", kind);
+  std::lock_guard<std::mutex> lk(esc::g_prof_mu);
+  esc::g_prof[kind].on = on != 0;
+  return ESC_OK;
+}
+
+int esc_prof_reset(int kind) {
+  ESC_REQUIRE(kind >= 0 && kind < ESC_K_COUNT, "esc_prof_reset: bad kind %d", kind);
+  std::lock_guard<std::mutex> lk(esc::g_prof_mu);
+  esc::g_prof[kind].used = 0;
+  return ESC_OK;
+}
+
+int esc_prof_read(int kind, int64_t* launches, double* total_ms) {
+  ESC_REQUIRE(kind >= 0 && kind < ESC_K_COUNT && launches && total_ms, "esc_prof_read: bad argument");
+  std::lock_guard<std::mutex> lk(esc::g_prof_mu);
+  esc::ProfState& p = esc::g_prof[kind];
+  double tot = 0;
+  for (size_t i = 0; i < p.used; ++i) {
+    if (hipEventSynchronize(p.stop[i]) != hipSuccess) {
+      esc::set_error("esc_prof_read: event sync failed");
+      return ESC_ELAUNCH;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, p.start[i], p.stop[i]);
+    tot += ms;
+  }
+  *launches = (int64_t)p.used;
+  *total_ms = tot;
+  return ESC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""torch.nn-compatible layers whose arithmetic runs in libescgnn_hip.so.
+
+`Linear` keeps torch.nn.Linear's parameters / init / state_dict keys but multiplies on the fp32
+matrix cores; `GINEConv` mirrors the constructor and state_dict layout of PyG 2.0.4's GINEConv as
+the reference instantiates it (run_graphcount.py:77-89,97-109: nn=Sequential(...), train_eps=True,
+edge_dim=hidden -> parameters `eps`, `nn.*`, `lin.{weight,bias}`).
+"""
+import torch
+
+from . import ops
+from .plan import plan_of
+
+
+class Linear(torch.nn.Linear):
+    def forward(self, x):
+        lead = x.shape[:-1]
+        y = ops.linear(x.reshape(-1, x.shape[-1]), self.weight, self.bias)
+        return y.view(*lead, self.out_features)
+
+
+class BatchNorm1d(torch.nn.BatchNorm1d):
+    """torch.nn.BatchNorm1d (same parameters/buffers/state_dict) computed by the HIP norm kernels.
+    `fuse_relu=True` also applies the ReLU that follows it in the reference's Sequential (the
+    ReLU module stays in place as `AbsorbedReLU` so the child indices / checkpoint keys match)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, fuse_relu=False):
+        super().__init__(num_features, eps=eps, momentum=momentum)
+        self.fuse_relu = fuse_relu
+
+    def forward(self, x):
+        if x.dim() != 2:
+            raise ValueError("expected 2D input (got {}D input)".format(x.dim()))
+        if self.training:
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                      self.eps, self.momentum, self.fuse_relu)
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            y = torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                                               False, 0.0, self.eps)
+            return torch.relu(y) if self.fuse_relu else y
+        return ops.bn_eval_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                               self.fuse_relu)
+
+
+class AbsorbedReLU(torch.nn.ReLU):
+    """Placeholder for a ReLU whose work is fused into the preceding BatchNorm1d(fuse_relu=True)."""
+
+    def forward(self, x):
+        return x
+
+
+class GINEConv(torch.nn.Module):
+    """out = nn( sum_{j->i} relu(x_j + lin(e_ji)) + (1 + eps) * x_i )"""
+
+    def __init__(self, nn, eps=0.0, train_eps=False, edge_dim=None):
+        super().__init__()
+        self.nn = nn
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = torch.nn.Parameter(torch.Tensor([eps]))
+        else:
+            self.register_buffer("eps", torch.Tensor([eps]))
+        first = nn[0]
+        in_channels = first.in_features if hasattr(first, "in_features") else first.in_channels
+        self.lin = Linear(edge_dim, in_channels) if edge_dim is not None else None
+
+    def reset_parameters(self):
+        for m in self.nn.modules():
+            if m is not self.nn and hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        self.eps.data.fill_(self.initial_eps)
+        if self.lin is not None:
+            self.lin.reset_parameters()
+
+    def forward(self, x, edge_index, edge_attr=None, plan=None):
+        if plan is None:
+            from .plan import BatchPlan
+            plan = BatchPlan.from_tensors(edge_index, x.size(0))
+        if self.lin is None and x.size(-1) != edge_attr.size(-1):
+            raise ValueError("Node and edge feature dimensionalities do not match. "
+                             "Consider setting the 'edge_dim' attribute of 'GINEConv'")
+        e = self.lin(edge_attr) if self.lin is not None else edge_attr
+        return self.nn(ops.gine_aggregate(x, e, self.eps, plan))
+
+    def __repr__(self):
+        return "{}(nn={})".format(self.__class__.__name__, self.nn)
+
+
+def global_add_pool(x, batch, size=None):
+    """segment sum by graph id (PyG global_add_pool).  Small [N,C]->[G,C]; torch index_add_."""
+    size = int(batch.max()) + 1 if size is None else size
+    return x.new_zeros((size, x.size(1))).index_add_(0, batch, x)
+
+
+def global_mean_pool(x, batch, size=None):
+    size = int(batch.max()) + 1 if size is None else size
+    cnt = torch.bincount(batch, minlength=size).clamp(min=1).to(x.dtype)
+    return global_add_pool(x, batch, size) / cnt.view(-1, 1)

@@ -1,0 +1,238 @@
+"""Autograd bindings of the HIP hot-path kernels (ctypes -> libescgnn_hip.so, C ABI in
+include/escgnn_hip.h).  Each Function names the reference call site it replaces.  There is no
+CPU or PyTorch fallback: a CPU tensor raises.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _native as nv
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("esc_gnn_amd: the hot path runs on the HIP device only (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError("esc_gnn_amd: expected float32, got %s" % t.dtype)
+
+
+def _rows(t):
+    """2-D, unit inner stride view + its leading dimension."""
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D tensor, got shape %s" % (tuple(t.shape),))
+    if t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1)):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.size(0) > 1 else t.size(1))
+
+
+class _Bag(Function):
+    """z_emb = global_add_pool(z_initial.weight[pos_index] * pos_enc[:,None], pos_batch)
+    (run_graphcount.py:155) as a CSR SpMM; backward = deterministic CSC segmented sum."""
+
+    @staticmethod
+    def forward(ctx, table, plan):
+        _dev(table)
+        table = table.contiguous()
+        if plan.row_ptr is None:
+            raise ValueError("batch has no pos_enc/pos_index/pos_batch")
+        E, H = plan.num_edges, table.size(1)
+        out = torch.empty((E, H), dtype=torch.float32, device=table.device)
+        nv.call("esc_bag_fwd", nv.ptr(table), H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx),
+                nv.ptr(plan.bag_val), E, nv.ptr(out), H, nv.stream())
+        ctx.plan, ctx.shape = plan, tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        plan = ctx.plan
+        rows, H = ctx.shape
+        dz, ld = _rows(dz)
+        dtable = torch.empty((rows, H), dtype=torch.float32, device=dz.device)
+        scratch = torch.empty(max(1, nv.lib().esc_bag_bwd_scratch(plan.nnz, H)), dtype=torch.float32, device=dz.device)
+        nv.call("esc_bag_bwd_table", nv.ptr(dz), ld, H, nv.ptr(plan.col_ptr), nv.ptr(plan.col_row),
+                nv.ptr(plan.col_val), nv.ptr(plan.col_col), plan.nnz, rows, nv.ptr(dtable), nv.ptr(scratch),
+                nv.stream())
+        return dtable, None
+
+
+def esc_bag(table, plan):
+    return _Bag.apply(table, plan)
+
+
+class _GineAggregate(Function):
+    """out = sum_{k: dst_k=i} relu(x[src_k] + e_k) + (1+eps) x_i — PyG GINEConv propagate + self term
+    (run_graphcount.py:161,169; gine_conv_layer.py:56-84)."""
+
+    @staticmethod
+    def forward(ctx, x, e, eps, plan):
+        _dev(x, e, eps)
+        x, ldx = _rows(x)
+        e, lde = _rows(e)
+        N, C = x.shape
+        if e.shape != (plan.num_edges, C) or N != plan.num_nodes:
+            raise ValueError("aggregate: x %s / e %s do not match the batch (N=%d, E=%d)"
+                             % (tuple(x.shape), tuple(e.shape), plan.num_nodes, plan.num_edges))
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        nv.call("esc_gine_aggregate_fwd", nv.ptr(x), ldx, nv.ptr(e), lde, nv.ptr(plan.in_ptr),
+                nv.ptr(plan.in_edge), nv.ptr(plan.in_src), nv.ptr(eps), N, C, nv.ptr(out), C, nv.stream())
+        ctx.save_for_backward(x, e, eps)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e, eps = ctx.saved_tensors
+        plan = ctx.plan
+        g, ldg = _rows(g)
+        N, C = x.shape
+        need_dx, need_de, need_eps = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        d_e = torch.empty_like(e)
+        dx = torch.empty((N, C), dtype=torch.float32, device=x.device) if need_dx else None
+        part = torch.empty(N, dtype=torch.float32, device=x.device) if need_eps else None
+        nv.call("esc_gine_aggregate_bwd", nv.ptr(x), x.stride(0), nv.ptr(e), e.stride(0), nv.ptr(g), ldg,
+                nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, C,
+                nv.ptr(d_e), d_e.stride(0), nv.ptr(dx), C, nv.ptr(part), nv.stream())
+        deps = None
+        if need_eps:
+            deps = torch.empty(1, dtype=torch.float32, device=x.device)
+            nv.call("esc_reduce_sum", nv.ptr(part), N, nv.ptr(deps), nv.stream())
+        return dx, (d_e if need_de else None), deps, None
+
+
+def gine_aggregate(x, e, eps, plan):
+    return _GineAggregate.apply(x, e, eps, plan)
+
+
+class _Linear(Function):
+    """torch.nn.Linear on the fp32 matrix cores (every Linear of run_graphcount.py:54-121,183-189)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _dev(x, weight, bias)
+        x, ldx = _rows(x)
+        weight = weight.contiguous()
+        M, K = x.shape
+        N = weight.size(0)
+        if weight.size(1) != K:
+            raise ValueError("linear: x %s vs weight %s" % (tuple(x.shape), tuple(weight.shape)))
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        nv.call("esc_linear_fwd", nv.ptr(x), ldx, nv.ptr(weight), K, nv.ptr(bias), None, None, M, N, K,
+                nv.ptr(y), N, None, nv.stream())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy, ldy = _rows(dy)
+        M, K = x.shape
+        N = weight.size(0)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+            nv.call("esc_linear_bwd_input", nv.ptr(dy), ldy, nv.ptr(weight), K, M, N, K, nv.ptr(dx), K, 0,
+                    nv.stream())
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+            db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            if M == 0:
+                dw.zero_()
+                if db is not None:
+                    db.zero_()
+            else:
+                slabs = torch.empty(nv.lib().esc_linear_bwd_weight_scratch(M, N, K), dtype=torch.float32,
+                                    device=x.device)
+                nv.call("esc_linear_bwd_weight", nv.ptr(dy), ldy, nv.ptr(x), x.stride(0), None, None, M, N, K,
+                        nv.ptr(dw), K, nv.ptr(db), nv.ptr(slabs), nv.stream())
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+class _BatchNormAct(Function):
+    """Training-mode BatchNorm1d (+ optional fused ReLU): batch statistics, running-stat update and
+    normalisation (run_graphcount.py:55-60,66-72,80-87,115)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        _dev(x, gamma, beta)
+        x, ldx = _rows(x)
+        M, C = x.shape
+        if M <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(nv.lib().esc_bn_scratch(C), dtype=torch.float32, device=dev)
+        y = torch.empty((M, C), dtype=torch.float32, device=dev)
+        s = nv.stream()
+        nv.call("esc_bn_stats", nv.ptr(x), ldx, M, C, float(eps), float(momentum), nv.ptr(mean), nv.ptr(invstd),
+                nv.ptr(running_mean), nv.ptr(running_var), nv.ptr(scratch), s)
+        nv.call("esc_bn_apply", nv.ptr(x), ldx, M, C, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+                int(relu), nv.ptr(y), C, s)
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        ctx.relu, ctx.scratch = bool(relu), scratch
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy, ldg = _rows(dy)
+        M, C = x.shape
+        dx = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        nv.call("esc_bn_bwd", nv.ptr(x), x.stride(0), nv.ptr(y), C, nv.ptr(dy), ldg, M, C, nv.ptr(mean),
+                nv.ptr(invstd), nv.ptr(gamma), int(ctx.relu), nv.ptr(dx), C, nv.ptr(dgamma), nv.ptr(dbeta),
+                nv.ptr(ctx.scratch), nv.stream())
+        return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, eps, momentum, relu)
+
+
+def bn_eval_act(x, gamma, beta, running_mean, running_var, eps, relu):
+    """Inference-mode BatchNorm (+ReLU) with running statistics — no autograd (eval/no_grad path)."""
+    _dev(x)
+    x, ldx = _rows(x)
+    M, C = x.shape
+    invstd = torch.rsqrt(running_var + eps)
+    y = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    nv.call("esc_bn_apply", nv.ptr(x), ldx, M, C, nv.ptr(running_mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+            int(relu), nv.ptr(y), C, nv.stream())
+    return y
+
+
+class _L1Loss(Function):
+    """torch.nn.L1Loss()(pred, y) (run_graphcount.py:500-501); `denom` overrides the mean's divisor
+    (global node count under graph-sharded data parallelism)."""
+
+    @staticmethod
+    def forward(ctx, pred, y, denom):
+        _dev(pred, y)
+        pred = pred.contiguous().view(-1)
+        y = y.contiguous().view(-1)
+        if pred.numel() != y.numel():
+            raise ValueError("l1_loss: %d predictions vs %d targets" % (pred.numel(), y.numel()))
+        M = pred.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty(M, dtype=torch.float32, device=pred.device)
+        nv.call("esc_l1_loss", nv.ptr(pred), nv.ptr(y), M, int(denom or M), 1.0, nv.ptr(loss), nv.ptr(dpred), nv.stream())
+        ctx.save_for_backward(dpred)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return (dpred * g).view(-1, 1), None, None
+
+
+def l1_loss(pred, y, denom=None):
+    return _L1Loss.apply(pred, y, denom)

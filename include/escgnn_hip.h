@@ -1,0 +1,129 @@
+/* escgnn_hip.h — C ABI of libescgnn_hip.so: the MI355X (gfx950) hot path of ESC-GNN's
+ * NestedGIN_eff: ego-net structural-encoding feature build, collate, ESC bag, GINE aggregate,
+ * fp32-MFMA linear layers, BatchNorm/ReLU, L1 loss and Adam.
+ *
+ * Plain pointers + sizes only (no torch types).  All pointers are DEVICE pointers unless a
+ * parameter is documented "host".  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Every function returns 0 on success or a negative ESC_E* code; esc_last_error()
+ * returns a human-readable message for the calling thread.  Nothing here allocates device
+ * memory or synchronises the stream unless documented: the caller owns every buffer
+ * (SURVEY.md §8(b) "Ownership"), so the calls are hipGraph-capturable.
+ *
+ * The reference has no FFI for this path (it is pure Python on PyG); each entry point names
+ * the reference call site (file:line under /root/reference) whose device work it replaces.
+ * Index arrays are int32 ("compact") unless stated; user-visible int64 tensors are produced
+ * only by esc_collate_* / esc_features_fill so they stay bit-identical to the reference's.
+ */
+#ifndef ESCGNN_HIP_H
+#define ESCGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESC_OK 0
+#define ESC_EINVAL (-1)   /* bad argument (null pointer, negative size, misaligned, unsupported width) */
+#define ESC_ELAUNCH (-2)  /* HIP runtime error at launch */
+#define ESC_ERANGE (-3)   /* input outside the encodable range (degree>=200, rd bin>=100, h>4, n too large) */
+
+int esc_abi_version(void);                /* bumps when a signature changes */
+const char* esc_last_error(void);         /* message of the last failing call on this thread */
+
+/* ---- profiling hook: HIP-event timing of one kernel family on its own launch stream ------ */
+enum { ESC_K_AGG_FWD = 0, ESC_K_AGG_BWD = 1, ESC_K_BAG_FWD = 2, ESC_K_BAG_BWD = 3,
+       ESC_K_LINEAR = 4, ESC_K_COLLATE = 5, ESC_K_FEATURES = 6, ESC_K_NORM = 7, ESC_K_COUNT = 8 };
+int esc_prof_enable(int kind, int on);    /* on!=0: bracket every launch of `kind` with events */
+int esc_prof_read(int kind, int64_t* launches, double* total_ms);  /* host; syncs recorded events */
+int esc_prof_reset(int kind);
+
+/* ---- a-6 ESC bag: z[k,:] = sum_j val_j * W[idx_j,:]  (run_graphcount.py:155) -------------
+ * forward order = entry order inside the row with separate mul/add roundings, i.e. bitwise what
+ * a sequential scatter_add of (W[idx]*val) produces. */
+int esc_bag_fwd(const float* table, int64_t H, const int32_t* row_ptr, const int32_t* idx32,
+                const int32_t* val32, int64_t E, float* out, int64_t ld_out, void* stream);
+/* dTable[c,:] = sum_{j: idx_j=c} val_j * dZ[row_j,:] — deterministic two-pass segmented sum over
+ * the CSC view; `partials` = esc_bag_bwd_scratch(Z,H) floats of scratch.  Writes ALL n_cols rows
+ * (zeros where a column has no entry). */
+int64_t esc_bag_bwd_scratch(int64_t Z, int64_t H);
+int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
+                      const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
+                      int64_t n_cols, float* dtable, float* partials, void* stream);
+
+/* ---- a-8 GINE aggregate (PyG GINEConv propagate; run_graphcount.py:161,169;
+ * semantics GraphGPS/graphgps/layer/gine_conv_layer.py:56-84) -------------------------------
+ * out[i,:] = (1+eps)*x[i,:] + sum_{k in in(i), ascending k} relu(x[src_k,:] + e[k,:]).
+ * in_ptr/in_edge/in_src = CSR by destination from esc_csr_build(key=dst, other=src).
+ * eps: device scalar.  Leading dimensions in floats. */
+int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t ld_e,
+                           const int32_t* in_ptr, const int32_t* in_edge, const int32_t* in_src,
+                           const float* eps, int64_t N, int64_t C, float* out, int64_t ld_out,
+                           void* stream);
+/* backward, CSR by source (out_ptr/out_edge/out_dst): d_e[k,:] = [x[src_k]+e_k > 0] * g[dst_k,:];
+ * dx[i,:] = (1+eps)*g[i,:] + sum_{k in out(i)} d_e[k,:]  (dx may be NULL);
+ * deps_part[i] = sum_c g[i,c]*x[i,c]  (deps_part may be NULL). */
+int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t ld_e,
+                           const float* g, int64_t ld_g, const int32_t* out_ptr,
+                           const int32_t* out_edge, const int32_t* out_dst, const float* eps,
+                           int64_t N, int64_t C, float* d_e, int64_t ld_de, float* dx,
+                           int64_t ld_dx, float* deps_part, void* stream);
+
+/* deterministic sum of n floats (fp64 accumulation) -> out[0]; finishes deps from deps_part. */
+int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream);
+
+/* ---- a-7/a-8/a-9/a-10 dense layers on the matrix cores (exact-fp32 MFMA) -----------------
+ * torch.nn.Linear call sites run_graphcount.py:54-121,183-189 (+ GINEConv.lin).
+ * Y[M,N] = act(X)[M,K] * W[N,K]^T + bias[N]   (bias may be NULL)
+ * act(X) = X, or relu(X*in_scale[k] + in_shift[k]) when in_scale != NULL (fused BN+ReLU of the
+ * producer layer).  col_stats (may be NULL): float[ceil(M/128)][2][N] per-row-tile partial
+ * (sum, sum of squares) of Y for a following BatchNorm. */
+int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                   const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
+                   float* Y, int64_t ld_y, float* col_stats, void* stream);
+/* dX[M,K] = dY[M,N] * W[N,K]  (accumulate!=0: dX += ...) */
+int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
+                         int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate,
+                         void* stream);
+/* dW[N,K] = dY[M,N]^T * act(X)[M,K], db[N] = colsum(dY) (db may be NULL).
+ * `slabs` = float scratch of esc_linear_bwd_weight_scratch(M,N,K) floats (split-M partials,
+ * summed in fixed order => bitwise reproducible). */
+int64_t esc_linear_bwd_weight_scratch(int64_t M, int64_t N, int64_t K);
+int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x,
+                          const float* in_scale, const float* in_shift, int64_t M, int64_t N,
+                          int64_t K, float* dW, int64_t ld_dw, float* db, float* slabs,
+                          void* stream);
+
+/* ---- BatchNorm1d (training statistics) + ReLU, torch.nn.BatchNorm1d call sites
+ * run_graphcount.py:55-60,66-72,80-87,115 --------------------------------------------------
+ * stats: mean[C], invstd[C] of X[M,C] (biased variance, eps), optional running-stat update
+ * (momentum, unbiased variance) exactly as torch does; then Y = relu?(gamma*(X-mean)*invstd+beta). */
+int64_t esc_bn_scratch(int64_t C);      /* floats of scratch the three calls below need */
+int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, float momentum,
+                 float* mean, float* invstd, float* running_mean, float* running_var,
+                 float* scratch, void* stream);
+int esc_bn_apply(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* mean,
+                 const float* invstd, const float* gamma, const float* beta, int relu, float* Y,
+                 int64_t ld_y, void* stream);
+/* backward of Y = relu?(BN(X)): dX, dgamma[C], dbeta[C].  Y is the forward output (relu mask;
+ * may be NULL when relu == 0). */
+int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
+               int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
+               const float* gamma, int relu, float* dX, int64_t ld_dx, float* dgamma, float* dbeta,
+               float* scratch, void* stream);
+
+/* ---- a-11 loss + optimiser (run_graphcount.py:478,500-505) -------------------------------- */
+/* loss[0] = sum_i |pred_i - y_i| / denom ; dpred_i = sign(pred_i - y_i) * grad_scale / denom
+ * (dpred may be NULL).  denom = M for the reference's L1Loss(mean); = global node count under
+ * graph-sharded data parallelism. */
+int esc_l1_loss(const float* pred, const float* y, int64_t M, int64_t denom, float grad_scale,
+                float* loss, float* dpred, void* stream);
+/* torch.optim.Adam (no amsgrad, no weight decay) over one flat buffer, torch's operation order;
+ * `step` is the 1-based step number. */
+int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESCGNN_HIP_H */

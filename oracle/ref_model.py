@@ -1,0 +1,123 @@
+"""ORACLE (test infrastructure, not product code): pure-PyTorch CPU restatement of the
+NestedGIN_eff message-passing path, op-for-op what PyG 2.0.4 dispatches to on CPU
+(index_select gather -> relu(x_j + e) -> scatter-add; global_add_pool = scatter-add).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this.
+
+Follows:
+  * GINEConv semantics         /root/reference/GraphGPS/graphgps/layer/gine_conv_layer.py:18-84
+                               (minus its r_ij factor) and the call sites
+                               /root/reference/run_graphcount.py:77-89,97-109,161,169
+  * ESC bag (global_add_pool)  /root/reference/run_graphcount.py:155
+  * model composition          /root/reference/run_graphcount.py:39-194
+  * loss / optimiser           /root/reference/run_graphcount.py:478-505
+
+Parity status: the three PyG primitives (GINEConv, global_add_pool, global_mean_pool) live in
+the un-vendored dependency torch-geometric==2.0.4 (requirements.txt:94); no reference test pins
+them => "parity unpinned" at that boundary.  The *composition* is pinned: make_golden.py execs
+the reference's own NestedGIN_eff class body on top of these primitives and the result is
+compared with NestedGINEffRef below (tests/golden/model_count.npz).
+"""
+import torch
+import torch.nn.functional as F
+from torch.nn import BatchNorm1d, Dropout, Linear, ReLU, Sequential
+
+
+def global_add_pool(x, batch, size=None):
+    """PyG: scatter(x, batch, dim=0, dim_size=batch.max()+1, reduce='add')."""
+    size = int(batch.max()) + 1 if size is None else size
+    out = x.new_zeros((size,) + tuple(x.shape[1:]))
+    return out.index_add_(0, batch, x)
+
+
+def global_mean_pool(x, batch, size=None):
+    size = int(batch.max()) + 1 if size is None else size
+    s = global_add_pool(x, batch, size)
+    cnt = torch.zeros(size, dtype=x.dtype).index_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
+    return s / cnt.clamp(min=1).view(-1, *([1] * (x.dim() - 1)))
+
+
+class GINEConv(torch.nn.Module):
+    """out = nn( sum_{k: dst_k = i} relu(x[src_k] + lin(edge_attr_k)) + (1+eps) * x_i )."""
+
+    def __init__(self, nn, eps=0.0, train_eps=False, edge_dim=None):
+        super().__init__()
+        self.nn = nn
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = torch.nn.Parameter(torch.Tensor([eps]))
+        else:
+            self.register_buffer("eps", torch.Tensor([eps]))
+        self.lin = Linear(edge_dim, nn[0].in_features) if edge_dim is not None else None
+
+    def reset_parameters(self):
+        for m in self.nn:
+            if hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        self.eps.data.fill_(self.initial_eps)
+        if self.lin is not None:
+            self.lin.reset_parameters()
+
+    def forward(self, x, edge_index, edge_attr):
+        e = self.lin(edge_attr) if self.lin is not None else edge_attr
+        msg = (x.index_select(0, edge_index[0]) + e).relu()
+        out = torch.zeros_like(x).index_add_(0, edge_index[1], msg)
+        out = out + (1 + self.eps) * x
+        return self.nn(out)
+
+
+def _mlp(i, h, p):
+    return Sequential(Linear(i, h), Dropout(p), BatchNorm1d(h), ReLU(),
+                      Linear(h, h), Dropout(p), BatchNorm1d(h), ReLU())
+
+
+class NestedGINEffRef(torch.nn.Module):
+    """Same module tree / state_dict keys as run_graphcount.py:39-121, forward :134-194."""
+
+    def __init__(self, num_layers, hidden, graph_pred=False, dropout=0.0, use_cycle=True,
+                 num_classes=1, input_dim=10, z_in=1800):
+        super().__init__()
+        self.graph_pred, self.dropout, self.use_cycle = graph_pred, dropout, use_cycle
+        self.z_initial = torch.nn.Embedding(z_in, hidden)
+        self.z_embedding = Sequential(Dropout(dropout), BatchNorm1d(hidden), ReLU(), Linear(hidden, hidden),
+                                      Dropout(dropout), BatchNorm1d(hidden), ReLU())
+        self.x_embedding = _mlp(input_dim, hidden, dropout)
+        self.conv1 = GINEConv(_mlp(input_dim, hidden, dropout), train_eps=True, edge_dim=hidden)
+        self.convs = torch.nn.ModuleList(
+            [GINEConv(_mlp(hidden, hidden, dropout), train_eps=True, edge_dim=hidden)
+             for _ in range(num_layers - 1)])
+        self.lin1 = Linear(num_layers * hidden + hidden, hidden)
+        self.bn_lin1 = BatchNorm1d(hidden, eps=1e-5, momentum=0.1)
+        self.lin2 = Linear(hidden, 1 if use_cycle else num_classes)
+
+    def bag(self, pos_enc, pos_index, pos_batch, num_edges=None):
+        return global_add_pool(self.z_initial.weight[pos_index] * pos_enc.view(-1, 1), pos_batch, num_edges)
+
+    def forward(self, x, edge_index, pos_enc, pos_index, pos_batch, batch=None, return_embeddings=False):
+        z = self.z_embedding(self.bag(pos_enc, pos_index, pos_batch))
+        h = self.conv1(x, edge_index, z)
+        xs = [self.x_embedding(x), h]
+        for conv in self.convs:
+            h = conv(h, edge_index, z)
+            xs.append(h)
+        cat = torch.cat(xs, dim=1)
+        if self.graph_pred:
+            cat = global_mean_pool(cat, batch)
+        o = self.lin1(cat)
+        if o.size(0) > 1:
+            o = self.bn_lin1(o)
+        o = F.dropout(F.relu(o), p=self.dropout, training=self.training)
+        o = self.lin2(o)
+        if not self.use_cycle:
+            o = F.log_softmax(o, dim=-1)
+        return (o, cat) if return_embeddings else o
+
+
+def train_step(model, optimizer, b):
+    """One optimisation step as run_graphcount.py:494-505 (L1 loss, mean over nodes)."""
+    optimizer.zero_grad()
+    pred = model(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b.get("batch"))
+    loss = F.l1_loss(pred, b["y"].view(-1, 1))
+    loss.backward()
+    optimizer.step()
+    return loss.detach()

@@ -1,0 +1,171 @@
+"""Parity of each HIP kernel family with the CPU oracle (through the C ABI via ctypes).
+
+Integer/index-driven sums with a defined order (bag forward, aggregate forward) must be
+BIT-EXACT against the oracle's sequential scatter; matrix-core and reduction kernels are held to
+rtol=atol=1e-5 against an fp64 reference (north_star tolerance: 1e-5 fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_collate, require_gpu
+import ref_model as rm
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def E():
+    require_gpu()
+    import esc_gnn_amd
+    return esc_gnn_amd
+
+
+def _batch(tag="count3"):
+    _, b, _ = load_collate(tag)
+    return {k: torch.tensor(v) for k, v in b.items()}
+
+
+def _plan(E, b, dev):
+    return E.BatchPlan.from_tensors(b["edge_index"].to(dev), b["x"].shape[0], b["pos_enc"].to(dev),
+                                    b["pos_index"].to(dev), b["pos_batch"].to(dev))
+
+
+@pytest.mark.parametrize("H", [256, 64, 300, 10])
+def test_bag_forward_bit_exact_and_backward(E, H):
+    torch.manual_seed(H)
+    dev = torch.device("cuda:0")
+    b = _batch("mixed4")
+    plan = _plan(E, b, dev)
+    W = torch.randn(1800, H)
+    torch.set_num_threads(1)
+    ref = rm.global_add_pool(W[b["pos_index"]] * b["pos_enc"].view(-1, 1), b["pos_batch"], plan.num_edges)
+    Wd = W.to(dev).requires_grad_(True)
+    out = E.ops.esc_bag(Wd, plan)
+    assert torch.equal(out.cpu(), ref), "bag forward must be bitwise a sequential scatter_add"
+    g = torch.randn_like(ref)
+    out.backward(g.to(dev))
+    gref = torch.zeros(1800, H, dtype=torch.float64)
+    gref.index_add_(0, b["pos_index"], g.double()[b["pos_batch"]] * b["pos_enc"].double().view(-1, 1))
+    assert torch.allclose(Wd.grad.cpu().double(), gref, **TOL)
+    # deterministic: a second backward gives the same bits
+    Wd.grad = None
+    E.ops.esc_bag(Wd, plan).backward(g.to(dev))
+    g2 = Wd.grad.clone()
+    Wd.grad = None
+    E.ops.esc_bag(Wd, plan).backward(g.to(dev))
+    assert torch.equal(g2, Wd.grad)
+
+
+@pytest.mark.parametrize("C", [256, 10, 64, 300])
+def test_aggregate_forward_bit_exact_and_backward(E, C):
+    torch.manual_seed(C)
+    dev = torch.device("cuda:0")
+    b = _batch("mixed4")
+    plan = _plan(E, b, dev)
+    N, Ed = b["x"].shape[0], b["edge_index"].shape[1]
+    x, e, eps = torch.randn(N, C), torch.randn(Ed, C), torch.tensor([0.3])
+    ei = b["edge_index"]
+    torch.set_num_threads(1)
+    msg = (x.index_select(0, ei[0]) + e).relu()
+    ref = torch.zeros_like(x).index_add_(0, ei[1], msg)
+    ref = ref + (1 + eps) * x
+    xd, ed, epsd = (t.to(dev).requires_grad_(True) for t in (x, e, eps))
+    out = E.ops.gine_aggregate(xd, ed, epsd, plan)
+    assert torch.equal(out.cpu(), ref), "aggregate forward must equal the sequential scatter bit for bit"
+    g = torch.randn(N, C)
+    out.backward(g.to(dev))
+    x64, e64, eps64 = (t.double().requires_grad_(True) for t in (x, e, eps))
+    m64 = (x64.index_select(0, ei[0]) + e64).relu()
+    r64 = torch.zeros_like(x64).index_add(0, ei[1], m64) + (1 + eps64) * x64
+    r64.backward(g.double())
+    assert torch.allclose(xd.grad.cpu().double(), x64.grad, **TOL)
+    assert torch.allclose(ed.grad.cpu().double(), e64.grad, **TOL)
+    assert torch.allclose(epsd.grad.cpu().double(), eps64.grad, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (333, 256, 10), (777, 10, 256), (130, 256, 1280),
+                                   (257, 1, 256), (9000, 256, 256), (5, 48, 36)])
+def test_linear_forward_backward(E, M, N, K):
+    torch.manual_seed(M + N + K)
+    dev = torch.device("cuda:0")
+    x, w, bias = torch.randn(M, K), torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, bias))
+    y = E.ops.linear(xd, wd, bd)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, bias))
+    r = x64 @ w64.t() + b64
+    assert torch.allclose(y.cpu().double(), r, **TOL)
+    g = torch.randn(M, N)
+    y.backward(g.to(dev))
+    r.backward(g.double())
+    assert torch.allclose(xd.grad.cpu().double(), x64.grad, **TOL)
+    scale = max(1.0, float(w64.grad.abs().max()))
+    assert torch.allclose(wd.grad.cpu().double() / scale, w64.grad / scale, **TOL)
+    assert torch.allclose(bd.grad.cpu().double() / scale, b64.grad / scale, **TOL)
+
+
+@pytest.mark.parametrize("M,C,relu", [(15200, 256, True), (2400, 256, False), (37, 10, True), (2, 300, True)])
+def test_batchnorm_relu(E, M, C, relu):
+    torch.manual_seed(M)
+    dev = torch.device("cuda:0")
+    x = torch.randn(M, C) * 3 + 5
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    rm0, rv0 = torch.randn(C), torch.rand(C) + 0.5
+    xd, gd, bd = (t.to(dev).requires_grad_(True) for t in (x, gamma, beta))
+    rmd, rvd = rm0.to(dev), rv0.to(dev)
+    y = E.ops.batch_norm_act(xd, gd, bd, rmd, rvd, 1e-5, 0.1, relu)
+    x64, g64, b64 = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    rm64, rv64 = rm0.double(), rv0.double()
+    r = torch.nn.functional.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    r = r.relu() if relu else r
+    assert torch.allclose(y.cpu().double(), r, **TOL)
+    assert torch.allclose(rmd.cpu().double(), rm64, **TOL) and torch.allclose(rvd.cpu().double(), rv64, **TOL)
+    g = torch.randn(M, C)
+    y.backward(g.to(dev))
+    r.backward(g.double())
+    assert torch.allclose(xd.grad.cpu().double(), x64.grad, **TOL)
+    s = max(1.0, float(g64.grad.abs().max()))
+    assert torch.allclose(gd.grad.cpu().double() / s, g64.grad / s, **TOL)
+    assert torch.allclose(bd.grad.cpu().double() / s, b64.grad / s, **TOL)
+
+
+def test_l1_loss_and_adam(E):
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    p, y = torch.randn(2400, 1), torch.randn(2400)
+    pd = p.to(dev).requires_grad_(True)
+    loss = E.ops.l1_loss(pd, y.to(dev))
+    p64 = p.double().requires_grad_(True)
+    r = torch.nn.functional.l1_loss(p64, y.double().view(-1, 1))
+    r.backward()
+    loss.backward()
+    assert abs(float(loss) - float(r)) < 1e-6
+    assert torch.allclose(pd.grad.cpu().double(), p64.grad, rtol=1e-6, atol=1e-9)
+    # Adam: 3 steps against torch.optim.Adam on CPU
+    from esc_gnn_amd.optim import FlatAdam
+    w = torch.randn(1000)
+    ref = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    mine = torch.nn.Parameter(w.clone().to(dev))
+    fopt = FlatAdam([mine], lr=1e-2)
+    for i in range(3):
+        g = torch.randn(1000)
+        ref.grad = g.clone()
+        opt.step()
+        fopt.flat_grad.copy_(g.to(dev))
+        fopt.step()
+    assert torch.allclose(fopt.params[0].detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_bad_arguments_raise(E):
+    dev = torch.device("cuda:0")
+    with pytest.raises((RuntimeError, ValueError)):
+        E.ops.linear(torch.zeros(4, 8, device=dev), torch.zeros(3, 7, device=dev), None)
+    b = _batch()
+    plan = _plan(E, b, dev)
+    with pytest.raises(ValueError):
+        E.ops.gine_aggregate(torch.zeros(3, 8, device=dev), torch.zeros(5, 8, device=dev),
+                             torch.zeros(1, device=dev), plan)
+    with pytest.raises(IndexError):
+        E.BatchPlan.from_tensors(b["edge_index"].to(dev), b["x"].shape[0], b["pos_enc"].to(dev),
+                                 (b["pos_index"] + 1800).to(dev), b["pos_batch"].to(dev))
