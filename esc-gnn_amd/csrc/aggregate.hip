@@ -19,6 +19,10 @@
 // Algorithmic bytes/launch: 2*E*C*4 + 2*N*C*4 + E*8 + (N+1)*4.
 #include "common.h"
 
+// Bitwise contract with the sequential CPU scatter: this file is compiled with -ffp-contract=off
+// (see Makefile) so a*b+c is never fused behind our back; explicit fmaf() calls still emit FMAs
+// where the order is free.
+
 namespace esc {
 
 // ---- wide rows: one wave per node, VEC floats per lane per pass ---------------------------------

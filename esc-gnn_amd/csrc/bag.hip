@@ -12,6 +12,10 @@
 // scalar unit and every table row is one coalesced 16 B/lane read (H=256 => exactly 1 KiB/wave).
 #include "common.h"
 
+// Bitwise contract with the sequential CPU scatter: this file is compiled with -ffp-contract=off
+// (see Makefile) so a*b+c is never fused behind our back; explicit fmaf() calls still emit FMAs
+// where the order is free.
+
 namespace esc {
 
 // ---- forward -----------------------------------------------------------------------------------

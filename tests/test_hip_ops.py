@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 TOL = dict(rtol=1e-5, atol=1e-5)
 
 
+def _chk(got, want, what, tol=1e-5):
+    got, want = got.detach().cpu().double(), want.detach().double()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max()) / scale
+    assert err <= tol, "%s: max error %.3g of scale %.3g > %g" % (what, err, scale, tol)
+
+
 @pytest.fixture(scope="module")
 def E():
     require_gpu()
@@ -47,7 +54,7 @@ def test_bag_forward_bit_exact_and_backward(E, H):
     out.backward(g.to(dev))
     gref = torch.zeros(1800, H, dtype=torch.float64)
     gref.index_add_(0, b["pos_index"], g.double()[b["pos_batch"]] * b["pos_enc"].double().view(-1, 1))
-    assert torch.allclose(Wd.grad.cpu().double(), gref, **TOL)
+    _chk(Wd.grad, gref, "table gradient")
     # deterministic: a second backward gives the same bits
     Wd.grad = None
     E.ops.esc_bag(Wd, plan).backward(g.to(dev))
@@ -123,10 +130,11 @@ def test_batchnorm_relu(E, M, C, relu):
     g = torch.randn(M, C)
     y.backward(g.to(dev))
     r.backward(g.double())
-    assert torch.allclose(xd.grad.cpu().double(), x64.grad, **TOL)
-    s = max(1.0, float(g64.grad.abs().max()))
-    assert torch.allclose(gd.grad.cpu().double() / s, g64.grad / s, **TOL)
-    assert torch.allclose(bd.grad.cpu().double() / s, b64.grad / s, **TOL)
+    # M=2: dx = (1 - xhat^2)(g1-g2)/2 with 1 - xhat^2 = eps/(var+eps) ~ 1e-6: ill-conditioned in ANY fp32
+    # implementation (torch's fp32 kernel shows the same), so only a loose bound is meaningful there.
+    _chk(xd.grad, x64.grad, "dx", tol=1e-5 if M > 2 else 2e-3)
+    _chk(gd.grad, g64.grad, "dgamma")
+    _chk(bd.grad, b64.grad, "dbeta")
 
 
 def test_l1_loss_and_adam(E):
@@ -139,7 +147,7 @@ def test_l1_loss_and_adam(E):
     r = torch.nn.functional.l1_loss(p64, y.double().view(-1, 1))
     r.backward()
     loss.backward()
-    assert abs(float(loss) - float(r)) < 1e-6
+    assert abs(float(loss.detach()) - float(r.detach())) < 1e-6
     assert torch.allclose(pd.grad.cpu().double(), p64.grad, rtol=1e-6, atol=1e-9)
     # Adam: 3 steps against torch.optim.Adam on CPU
     from esc_gnn_amd.optim import FlatAdam
