@@ -36,9 +36,13 @@ SIGNATURES = {
     "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, I32, P, I64, P, P, P, P],
     "esc_l1_loss": [P, P, I64, I64, F32, P, P, P],
     "esc_adam_step": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P],
+    "esc_features_scratch_bytes": [I64, I64, I64],
+    "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
+    "esc_features_fill": [P, P, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
 _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64,
-        "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64}
+        "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
+        "esc_features_scratch_bytes": c_int64}
 
 KIND = {"agg_fwd": 0, "agg_bwd": 1, "bag_fwd": 2, "bag_bwd": 3, "linear": 4, "collate": 5,
         "features": 6, "norm": 7}

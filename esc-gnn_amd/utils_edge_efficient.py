@@ -1,0 +1,132 @@
+"""`create_subgraphs`: the ESC-GNN pre_transform — per directed edge, the sparse 1800-bin structural
+histogram of its h-hop ego-net — computed by the HIP feature builder (csrc/features.hip).
+
+Drop-in for /root/reference/utils_edge_efficient.py:20-152 (same signature, same returned fields:
+x, edge_index' (self loops normalised), edge_attr' (loops filled with 1), y, pos_enc, pos_index,
+pos_batch — all index tensors int64 and bit-identical to the reference's).  `create_subgraphs_many`
+encodes a whole list of graphs in ONE pair of launches (the per-graph python loop of the
+reference's dataset `process()` — GraphCountDataset.py:113-116 — is where the hours go).
+"""
+import torch
+
+from . import _native as nv
+from .data import Data
+
+ESC_ERANGE = -3
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("esc_gnn_amd.create_subgraphs needs a HIP device (MI355X); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def encode_edge_lists(node_counts, edge_lists, h, use_rd, self_loop):
+    """Low-level batched call.  node_counts: list[int]; edge_lists: list of int64 [2, m_g] tensors with
+    graph-local ids.  Returns per-graph tuples (edge_index', in_edge_of_out, pos_enc, pos_index, pos_batch)
+    as CPU int64 tensors."""
+    dev = _device()
+    G = len(node_counts)
+    if G == 0:
+        return []
+    n_t = torch.tensor(node_counts, dtype=torch.int64)
+    m_t = torch.tensor([int(e.size(1)) for e in edge_lists], dtype=torch.int64)
+    node_ptr = torch.zeros(G + 1, dtype=torch.int64)
+    edge_ptr = torch.zeros(G + 1, dtype=torch.int64)
+    node_ptr[1:] = torch.cumsum(n_t, 0)
+    edge_ptr[1:] = torch.cumsum(m_t, 0)
+    Nn, Ein, nmax = int(node_ptr[-1]), int(edge_ptr[-1]), int(n_t.max())
+    cat = torch.cat([e.reshape(2, -1).to(torch.int64) for e in edge_lists], dim=1) if Ein else torch.zeros(2, 0, dtype=torch.int64)
+    src, dst = cat[0].contiguous().to(dev), cat[1].contiguous().to(dev)
+    node_ptr_d, edge_ptr_d = node_ptr.to(dev), edge_ptr.to(dev)
+    cap = Ein + (Nn if self_loop else 0)
+    out_edge_ptr = torch.empty(G + 1, dtype=torch.int64, device=dev)
+    nnz_ptr = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+    status = torch.zeros(G, dtype=torch.int32, device=dev)
+    work = torch.empty(nv.lib().esc_features_scratch_bytes(G, Nn, Ein), dtype=torch.uint8, device=dev)
+    s = nv.stream()
+    nv.call("esc_features_count", nv.ptr(node_ptr_d), nv.ptr(edge_ptr_d), nv.ptr(src), nv.ptr(dst), G, Nn, Ein, nmax,
+            int(h), int(bool(use_rd)), int(bool(self_loop)), nv.ptr(out_edge_ptr), nv.ptr(nnz_ptr), nv.ptr(status),
+            nv.ptr(work), s)
+    oep = out_edge_ptr.cpu()
+    Eout = int(oep[-1])
+    Z = int(nnz_ptr[Eout]) if cap else 0
+    out_src = torch.empty(Eout, dtype=torch.int64, device=dev)
+    out_dst = torch.empty(Eout, dtype=torch.int64, device=dev)
+    in_of_out = torch.empty(Eout, dtype=torch.int64, device=dev)
+    pos_enc = torch.empty(Z, dtype=torch.int64, device=dev)
+    pos_index = torch.empty(Z, dtype=torch.int64, device=dev)
+    pos_batch = torch.empty(Z, dtype=torch.int64, device=dev)
+    nv.call("esc_features_fill", nv.ptr(node_ptr_d), nv.ptr(edge_ptr_d), G, Nn, Ein, nmax, int(h),
+            int(bool(use_rd)), int(bool(self_loop)), nv.ptr(out_edge_ptr), nv.ptr(nnz_ptr), Eout, nv.ptr(out_src),
+            nv.ptr(out_dst), nv.ptr(in_of_out), nv.ptr(pos_enc), nv.ptr(pos_index), nv.ptr(pos_batch),
+            nv.ptr(status), nv.ptr(work), s)
+    st = status.cpu()
+    if bool((st != 0).any()):
+        g = int(torch.nonzero(st)[0])
+        raise RuntimeError("create_subgraphs: graph %d cannot be encoded (status %d): a sub-degree >= 200, a "
+                           "resistance-distance bin outside [0,100), an edge code >= 1300, a node id out of "
+                           "range, or an ego-net of more than 96 nodes with use_rd" % (g, int(st[g])))
+    nnz_c = nnz_ptr[:Eout + 1].cpu()
+    out_src, out_dst, in_of_out = out_src.cpu(), out_dst.cpu(), in_of_out.cpu()
+    pos_enc, pos_index, pos_batch = pos_enc.cpu(), pos_index.cpu(), pos_batch.cpu()
+    res = []
+    for g in range(G):
+        a, b = int(oep[g]), int(oep[g + 1])
+        za, zb = int(nnz_c[a]), int(nnz_c[b])
+        local_in = in_of_out[a:b].clone()
+        local_in[local_in >= 0] -= int(edge_ptr[g])
+        res.append((torch.stack([out_src[a:b], out_dst[a:b]]), local_in,
+                    pos_enc[za:zb], pos_index[za:zb], pos_batch[za:zb]))
+    return res
+
+
+def _num_nodes(data):
+    n = data.num_nodes
+    return int(n.item()) if torch.is_tensor(n) else int(n)
+
+
+def _rebuild(data, enc, self_loop):
+    edge_index, local_in, pos_enc, pos_index, pos_batch = enc
+    dev = data.edge_index.device
+    edge_attr = data.edge_attr
+    if self_loop and edge_attr is not None:
+        fill = edge_attr.new_full((edge_index.size(1),) + tuple(edge_attr.shape[1:]), 1)
+        keep = local_in >= 0
+        fill[keep.to(dev)] = edge_attr[local_in[keep].to(dev)]
+        edge_attr = fill
+    fields = dict(pos_enc=pos_enc.to(dev), pos_index=pos_index.to(dev), pos_batch=pos_batch.to(dev))
+    if "name" in data:                                   # reference :150-151
+        return data.__class__(data.x, edge_index.to(dev), edge_attr, data.y, data.pos, name=data.name,
+                              node_type=data["node_type"], **fields)
+    return data.__class__(data.x, edge_index.to(dev), edge_attr, data.y, None, **fields)
+
+
+def _check_args(h, max_nodes_per_hop, subgraph_pretransform):
+    if max_nodes_per_hop is not None:
+        raise NotImplementedError("max_nodes_per_hop (random neighbour sampling, reference :235-237) is not "
+                                  "part of the deterministic ESC hot path")
+    if subgraph_pretransform is not None:
+        raise NotImplementedError("subgraph_pretransform is the k-GNN baseline hook (reference :109-118)")
+    hs = [h] if isinstance(h, int) else list(h)
+    return int(hs[-1])                                   # only the last h of a list survives (:41,:152)
+
+
+def create_subgraphs(data, h=1, sample_ratio=1.0, max_nodes_per_hop=None, node_label='hop', use_rd=False,
+                     subgraph_pretransform=None, data_name=None, self_loop=False):
+    assert isinstance(data, Data)
+    h_last = _check_args(h, max_nodes_per_hop, subgraph_pretransform)
+    enc = encode_edge_lists([_num_nodes(data)], [data.edge_index.cpu()], h_last, use_rd, self_loop)[0]
+    return _rebuild(data, enc, self_loop)
+
+
+def create_subgraphs_many(data_list, h=1, use_rd=False, self_loop=False, chunk=4096):
+    """Encode many graphs with a handful of launches (chunked to bound device scratch)."""
+    h_last = _check_args(h, None, None)
+    out = []
+    for i in range(0, len(data_list), chunk):
+        part = data_list[i:i + chunk]
+        encs = encode_edge_lists([_num_nodes(d) for d in part], [d.edge_index.cpu() for d in part], h_last,
+                                 use_rd, self_loop)
+        out.extend(_rebuild(d, e, self_loop) for d, e in zip(part, encs))
+    return out
