@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — NestedGIN_eff training-step throughput on MI355X (the metric of BASELINE.json).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch: device collate + forward + L1 loss + backward +
+(gradient all-reduce when N>1) + Adam, on the synthetic count_cycle-shaped workload of SURVEY.md §8(d)
+(random regular graphs, h=3, rd + self loops, bs=128 PER GPU, L=4, H=256).  The pre-processed
+dataset (features from the HIP feature builder) is resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured-achievable
+MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch_size", type=int, default=128)
+    ap.add_argument("--graphs", type=int, default=1500, help="graphs in the (train) split kept in HBM per rank")
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--h", type=int, default=3)
+    ap.add_argument("--lr", type=float, default=1e-2)
+    ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no_breakdown", action="store_true")
+    return ap.parse_args()
+
+
+def linear_flops_per_step(N, E, H, L, in_dim=10):
+    """2*M*K*N per GEMM forward, x3 for forward + input grad + weight grad."""
+    f = 0
+    f += 2 * E * H * H                                   # z_embedding.3
+    f += 2 * E * H * in_dim + 2 * E * H * H * (L - 1)    # conv*.lin (edge term)
+    f += 2 * N * in_dim * H + 2 * N * H * H              # conv1.nn
+    f += (L - 1) * 2 * 2 * N * H * H                     # convs.nn
+    f += 2 * N * in_dim * H + 2 * N * H * H              # x_embedding
+    f += 2 * N * (L + 1) * H * H + 2 * N * H             # lin1, lin2
+    return 3 * f
+
+
+def aggregate_bytes(N, E, C):
+    """algorithmic bytes of one aggregate-forward launch."""
+    return 2 * E * C * 4 + 2 * N * C * 4 + E * 8 + (N + 1) * 4
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import esc_gnn_amd as E
+    from esc_gnn_amd import _native as nv
+    from esc_gnn_amd.datasets import build_count_dataset
+    from esc_gnn_amd.store import DeviceGraphStore
+
+    torch.manual_seed(0)
+    # ---- dataset: synthetic graphs -> HIP feature build -> HBM-resident store -----------------------
+    t0 = time.time()
+    first = rank * args.graphs                              # weak scaling: every rank owns its own split
+    graphs = build_count_dataset(first, args.graphs, h=args.h, use_rd=True, self_loop=True)
+    torch.cuda.synchronize()
+    t_feat = time.time() - t0
+    # y normalisation by mean/std of the split (run_graphcount.py:441-447)
+    y_all = torch.cat([g.y.view(-1) for g in graphs])
+    mean, std = y_all.mean(), y_all.std()
+    for g in graphs:
+        g.y = (g.y.view(-1) - mean) / std
+    store = DeviceGraphStore(graphs, dev)
+    nb = args.graphs // args.batch_size                     # full batches only, shuffle=False
+    batch_ids = [torch.arange(i * args.batch_size, (i + 1) * args.batch_size, device=dev) for i in range(nb)]
+
+    model = E.NestedGIN_eff(None, args.layers, args.hidden, use_rd=True, graph_pred=False, dropout=0,
+                            edge_nest=True, use_cycle=True).to(dev)
+    if world > 1:                                           # identical replicas
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    opt = E.optim.FlatAdam(model.parameters(), lr=args.lr)
+    model.train()
+
+    stats = dict(graphs=0, nodes=0, edges=0, nnz=0)
+
+    def step(i, count=False):
+        b = store.collate(batch_ids[i % nb])
+        opt.zero_grad()
+        pred = model(b)
+        loss = E.ops.l1_loss(pred, b.y)
+        loss.backward()
+        if world > 1:
+            dist.all_reduce(opt.flat_grad)
+            opt.flat_grad.div_(world)
+        opt.step()
+        if count:
+            stats["graphs"] += args.batch_size
+            stats["nodes"] += b.x.size(0)
+            stats["edges"] += b.edge_index.size(1)
+            stats["nnz"] += b.pos_enc.numel()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    # dominant-kernel timing with HIP events on the launch stream, inside the timed region
+    nv.prof_reset("agg_fwd")
+    nv.prof_enable("agg_fwd", True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, count=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    nv.prof_enable("agg_fwd", False)
+    n_agg, ms_agg = nv.prof_read("agg_fwd")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        tot = torch.tensor([stats["graphs"], stats["edges"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot)
+        total_graphs, total_edges = float(tot[0]), float(tot[1])
+    else:
+        total_graphs, total_edges = float(stats["graphs"]), float(stats["edges"])
+
+    # ---- per-family breakdown (separate instrumented steps, not part of `value`) -------------------
+    breakdown = {}
+    if not args.no_breakdown:
+        fams = ["agg_fwd", "agg_bwd", "bag_fwd", "bag_bwd", "linear", "norm", "collate"]
+        for f in fams:
+            nv.prof_reset(f)
+            nv.prof_enable(f, True)
+        k_extra = 5
+        for i in range(k_extra):
+            step(i)
+        torch.cuda.synchronize()
+        for f in fams:
+            nv.prof_enable(f, False)
+            n, ms = nv.prof_read(f)
+            breakdown[f] = dict(launches_per_step=n / k_extra, ms_per_step=ms / k_extra)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    N_avg = stats["nodes"] / args.steps
+    E_avg = stats["edges"] / args.steps
+    ms_step = elapsed / args.steps * 1e3
+    value = total_graphs / elapsed
+    edges_agg_per_s = total_edges * args.layers / elapsed
+
+    # roofline of the scatter-add (aggregate forward).  per step: 1 narrow launch (C=10) + (L-1) wide ones
+    alg_bytes = (aggregate_bytes(N_avg, E_avg, 10) + (args.layers - 1) * aggregate_bytes(N_avg, E_avg, args.hidden)) / args.layers
+    avg_ms = ms_agg / max(n_agg, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if n_agg else 0.0
+    roofline = dict(kernel="esc::agg_fwd_wave/agg_fwd_elem (GINE aggregate forward, the scatter-add)",
+                    bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    launches=n_agg, avg_us=round(avg_ms * 1e3, 2), alg_bytes_per_launch=int(alg_bytes))
+    extra = {}
+    if "linear" in breakdown and breakdown["linear"]["ms_per_step"] > 0:
+        fl = linear_flops_per_step(N_avg, E_avg, args.hidden, args.layers)
+        tf = fl / (breakdown["linear"]["ms_per_step"] * 1e-3) / 1e12
+        extra["roofline_mfma"] = dict(kernel="esc::gemm_tile_kernel (fp32 MFMA linears, fwd+dX+dW)", bound="mfma",
+                                      achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                                      frac=round(tf / MFMA_F32_PEAK_TF, 4), flops_per_step=int(fl))
+    cpu = cpu_baseline(args, graphs) if args.cpu_seconds > 0 else None
+
+    out = {
+        "metric": "graphs/sec + edges-aggregated/sec, NestedGIN_eff h=3 bs=128 @1/2/4/8 GPU",
+        "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "count_cycle-shaped random regular graphs (n in 10/15/20/30), target=triangles, "
+                               "NestedGIN_eff h=%d layers=%d hidden=%d, bs=%d per GPU (configs[1])"
+                               % (args.h, args.layers, args.hidden, args.batch_size),
+                   "global_batch": args.batch_size * world, "parallelism": "dp%d graph-sharded" % world,
+                   "nodes_per_batch": round(N_avg, 1), "edges_per_batch": round(E_avg, 1),
+                   "nnz_per_batch": round(stats["nnz"] / args.steps, 1)},
+        "edges_aggregated_per_s": round(edges_agg_per_s, 1),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "feature_build": {"graphs": args.graphs, "seconds": round(t_feat, 3),
+                          "note": "graph generation (networkx) + HIP create_subgraphs_many + host copies"},
+        "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in breakdown.items()},
+    }
+    out.update(extra)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, graphs):
+    """Reference path on the host cores: the oracle's pure-PyTorch NestedGIN_eff (what PyG 2.0.4 dispatches to
+    on CPU) + the host-side python collate, same batches, same hyper-parameters.  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_model as rm            # oracle: used here ONLY as the timed CPU baseline
+    import esc_gnn_amd as E
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("ESC_CPU_THREADS", "16"))))   # the box's CPU share per GPU is 16
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = rm.NestedGINEffRef(args.layers, args.hidden)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    model.train()
+    bs = args.batch_size
+    nb = len(graphs) // bs
+    times, done = [], 0
+    t_start = time.time()
+    i = 0
+    while True:
+        t0 = time.perf_counter()
+        b = E.Batch.from_data_list(graphs[(i % nb) * bs:(i % nb + 1) * bs])
+        bd = dict(x=b.x, edge_index=b.edge_index, pos_enc=b.pos_enc, pos_index=b.pos_index,
+                  pos_batch=b.pos_batch, batch=b.batch, y=b.y)
+        rm.train_step(model, opt, bd)
+        dt = time.perf_counter() - t0
+        if i >= 1:                      # first step = warm-up
+            times.append(dt)
+        i += 1
+        if (time.time() - t_start > args.cpu_seconds and len(times) >= 3) or len(times) >= 30:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(bs / med, 1), "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": "%d training steps (python collate + fwd + bwd + Adam) of the same bs=%d batches, median; "
+                      "torch %s, %d threads" % (len(times), bs, torch.__version__, torch.get_num_threads())}
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,20 @@ ABI_VERSION = 1
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
 
+class CollateArgs(ctypes.Structure):
+    """mirror of `esc_collate_args` (include/escgnn_hip.h)"""
+    _fields_ = ([(n, c_int64) for n in ("B", "x_dim", "y_dim", "n_cols")] +
+                [(n, c_void_p) for n in (
+                    "graph_ids", "offsets", "node_ptr", "edge_ptr", "nnz_ptr", "y_ptr", "x_all", "y_all",
+                    "esrc_all", "edst_all", "pos_enc_all", "pos_index_all", "pos_batch_all",
+                    "in_ptr_all", "in_edge_all", "out_ptr_all", "out_edge_all", "row_ptr_all", "c_perm_all",
+                    "c_rank_all", "col_ptr", "col_prefix",
+                    "x", "y", "edge_index", "batch", "pos_enc", "pos_index", "pos_batch",
+                    "in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst",
+                    "row_ptr", "bag_idx", "bag_val", "col_row", "col_val", "col_col")])
+
+
+
 # name -> argtypes (every function returns int unless listed in _RET)
 SIGNATURES = {
     "esc_abi_version": [],
@@ -36,6 +50,8 @@ SIGNATURES = {
     "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, I32, P, I64, P, P, P, P],
     "esc_l1_loss": [P, P, I64, I64, F32, P, P, P],
     "esc_adam_step": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P],
+    "esc_collate_cols": [P, I64, P, I64, P, P, P, P],
+    "esc_collate_fill": [POINTER(CollateArgs), P],
     "esc_features_scratch_bytes": [I64, I64, I64],
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
@@ -43,6 +59,8 @@ SIGNATURES = {
 _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
         "esc_features_scratch_bytes": c_int64}
+
+
 
 KIND = {"agg_fwd": 0, "agg_bwd": 1, "bag_fwd": 2, "bag_bwd": 3, "linear": 4, "collate": 5,
         "features": 6, "norm": 7}

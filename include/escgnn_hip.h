@@ -123,6 +123,43 @@ int esc_l1_loss(const float* pred, const float* y, int64_t M, int64_t denom, flo
 int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
+/* ---- a-5 collate (batch.py:25-149): gather B graphs out of the HBM-resident dataset store ------
+ * The store keeps the reference's InMemoryDataset layout (per-key concatenation + slice pointers,
+ * GraphCountDataset.py:119-120) plus views sorted ONCE at build time (suffix _all):
+ *   in_ptr_all[nodes+1] / in_edge_all[edges]   edges grouped by (global) destination, stable
+ *   out_ptr_all / out_edge_all                 edges grouped by source
+ *   row_ptr_all[edges+1]                       first bag entry of each edge
+ *   c_perm_all[nnz] / c_rank_all[nnz]          entries grouped by (graph, histogram bin) + rank inside the group
+ *   col_cnt_all[graphs][n_cols]                entries per bin per graph
+ * offsets = int64[4][B+1]: exclusive prefix sums of the selected graphs' node / edge / nnz / y-row
+ * counts (computed by the host from its copy of the slice pointers).
+ * Outputs: the reference's batch tensors (x, y, edge_index[2,E], batch, pos_enc, pos_index, pos_batch:
+ * int64 index tensors bit-identical to Batch.from_data_list) and the compact int32 plan consumed by
+ * esc_bag_* / esc_gine_aggregate_*. */
+typedef struct esc_collate_args {
+  int64_t B, x_dim, y_dim, n_cols;
+  const int64_t* graph_ids;     /* [B] device */
+  const int64_t* offsets;       /* [4][B+1] device */
+  /* store */
+  const int64_t *node_ptr, *edge_ptr, *nnz_ptr, *y_ptr;
+  const float *x_all, *y_all;
+  const int64_t *esrc_all, *edst_all, *pos_enc_all, *pos_index_all, *pos_batch_all;
+  const int64_t *in_ptr_all, *in_edge_all, *out_ptr_all, *out_edge_all, *row_ptr_all, *c_perm_all;
+  const int32_t* c_rank_all;
+  /* from esc_collate_cols */
+  const int32_t *col_ptr, *col_prefix;
+  /* reference-visible outputs */
+  float *x, *y;
+  int64_t *edge_index, *batch, *pos_enc, *pos_index, *pos_batch;
+  /* plan outputs */
+  int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
+  int32_t *row_ptr, *bag_idx, *bag_val, *col_row, *col_val, *col_col;
+} esc_collate_args;
+/* column bookkeeping of the batch: col_prefix[B][n_cols], col_total[n_cols], col_ptr[n_cols+1] */
+int esc_collate_cols(const int32_t* col_cnt_all, int64_t n_cols, const int64_t* graph_ids, int64_t B,
+                     int32_t* col_prefix, int32_t* col_total, int32_t* col_ptr, void* stream);
+int esc_collate_fill(const esc_collate_args* args /* host struct of device pointers */, void* stream);
+
 /* ---- a-1..a-4 feature build (utils_edge_efficient.py:20-152,201-294) -----------------------
  * G graphs per call.  node_ptr[G+1] / edge_ptr[G+1]: int64 prefix sums of node and input-edge
  * counts (the InMemoryDataset `slices` layout); src/dst: concatenated int64 edge lists with
