@@ -173,11 +173,12 @@ def main():
     value = total_graphs / elapsed
     edges_agg_per_s = total_edges * args.layers / elapsed
 
-    # roofline of the scatter-add (aggregate forward).  per step: 1 narrow launch (C=10) + (L-1) wide ones
-    alg_bytes = (aggregate_bytes(N_avg, E_avg, 10) + (args.layers - 1) * aggregate_bytes(N_avg, E_avg, args.hidden)) / args.layers
+    # roofline of the scatter-add: the row-per-wave aggregate-forward kernel, launched by the (L-1) layers of
+    # width `hidden` (the 10-wide first layer runs the narrow element kernel and is not in this average)
+    alg_bytes = aggregate_bytes(N_avg, E_avg, args.hidden)
     avg_ms = ms_agg / max(n_agg, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if n_agg else 0.0
-    roofline = dict(kernel="esc::agg_fwd_wave/agg_fwd_elem (GINE aggregate forward, the scatter-add)",
+    roofline = dict(kernel="esc::agg_fwd_wave<4> (GINE aggregate forward = the scatter-add, C=%d)" % args.hidden,
                     bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     launches=n_agg, avg_us=round(avg_ms * 1e3, 2), alg_bytes_per_launch=int(alg_bytes))

@@ -222,18 +222,17 @@ int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t
   if (N == 0) return ESC_OK;
   ESC_REQUIRE(e && in_edge && in_src, "esc_gine_aggregate_fwd: null edge arrays");
   hipStream_t s = (hipStream_t)stream;
-  esc::ProfScope prof(ESC_K_AGG_FWD, s);
   if (C >= 64) {
     const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_e % 4 == 0) && (ld_out % 4 == 0) &&
                      esc::aligned16(x) && esc::aligned16(e) && esc::aligned16(out);
     const int64_t blocks = esc::cdiv(N, 4);
     if (vec)
-      hipLaunchKernelGGL(esc::agg_fwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
     else
-      hipLaunchKernelGGL(esc::agg_fwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
   } else {
     const int64_t blocks = esc::cdiv(N * C, 256);
-    hipLaunchKernelGGL(esc::agg_fwd_elem, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+    esc::launch(-1, esc::agg_fwd_elem, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
   }
   ESC_CHECK_LAUNCH("esc_gine_aggregate_fwd");
   return ESC_OK;
@@ -255,18 +254,17 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                    (!dx || ld_dx % 4 == 0) && esc::aligned16(x) && esc::aligned16(e) && esc::aligned16(g) &&
                    esc::aligned16(d_e) && (!dx || esc::aligned16(dx));
   const int64_t blocks = esc::cdiv(N, 4);
-  esc::ProfScope prof(ESC_K_AGG_BWD, s);
   if (vec)
-    hipLaunchKernelGGL(esc::agg_bwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
   else
-    hipLaunchKernelGGL(esc::agg_bwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd");
   return ESC_OK;
 }
 
 int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream) {
   ESC_REQUIRE(out && (v || n == 0) && n >= 0, "esc_reduce_sum: bad argument");
-  hipLaunchKernelGGL(esc::reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out);
+  esc::launch(-1, esc::reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out);
   ESC_CHECK_LAUNCH("esc_reduce_sum");
   return ESC_OK;
 }

@@ -197,11 +197,10 @@ int esc_bag_fwd(const float* table, int64_t H, const int32_t* row_ptr, const int
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (H % 4 == 0) && (ld_out % 4 == 0) && esc::aligned16(table) && esc::aligned16(out);
   const int64_t blocks = esc::cdiv(E, 4);
-  esc::ProfScope prof(ESC_K_BAG_FWD, s);
   if (vec)
-    hipLaunchKernelGGL(esc::bag_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
+    esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
   else
-    hipLaunchKernelGGL(esc::bag_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
+    esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
   ESC_CHECK_LAUNCH("esc_bag_fwd");
   return ESC_OK;
 }
@@ -217,21 +216,20 @@ int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* 
   ESC_REQUIRE(Z < (1LL << 31) - 64, "esc_bag_bwd_table: Z too large");
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (H % 4 == 0) && (ld_dz % 4 == 0) && esc::aligned16(dz) && esc::aligned16(dtable) && esc::aligned16(partials);
-  esc::ProfScope prof(ESC_K_BAG_BWD, s);
   if (Z > 0) {
     const int64_t chunks = esc::cdiv(Z, esc::BAG_CH);
     const int64_t blocks = esc::cdiv(chunks, 4);
     if (vec)
-      hipLaunchKernelGGL(esc::bag_bwd_pass1<4>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
+      esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass1<4>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
     else
-      hipLaunchKernelGGL(esc::bag_bwd_pass1<1>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
+      esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass1<1>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
     ESC_CHECK_LAUNCH("esc_bag_bwd_table.pass1");
   }
   const int64_t blocks2 = esc::cdiv(n_cols, 4);
   if (vec)
-    hipLaunchKernelGGL(esc::bag_bwd_pass2<4>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
+    esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass2<4>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
   else
-    hipLaunchKernelGGL(esc::bag_bwd_pass2<1>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
+    esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass2<1>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
   ESC_CHECK_LAUNCH("esc_bag_bwd_table.pass2");
   return ESC_OK;
 }

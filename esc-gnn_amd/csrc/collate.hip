@@ -118,10 +118,9 @@ int esc_collate_cols(const int32_t* col_cnt_all, int64_t n_cols, const int64_t* 
   ESC_REQUIRE(col_cnt_all && graph_ids && col_prefix && col_total && col_ptr, "esc_collate_cols: null pointer");
   ESC_REQUIRE(n_cols > 0 && B > 0 && B < (1 << 24), "esc_collate_cols: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(ESC_K_COLLATE, s);
-  hipLaunchKernelGGL(collate_col_count_kernel, dim3((unsigned)cdiv(n_cols, 256)), dim3(256), 0, s, col_cnt_all, (int)n_cols, graph_ids, (int)B, col_prefix, col_total);
+  esc::launch(ESC_K_COLLATE, collate_col_count_kernel, dim3((unsigned)cdiv(n_cols, 256)), dim3(256), 0, s, col_cnt_all, (int)n_cols, graph_ids, (int)B, col_prefix, col_total);
   ESC_CHECK_LAUNCH("esc_collate_cols.count");
-  hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, col_total, (int)n_cols, col_ptr);
+  esc::launch(ESC_K_COLLATE, small_scan_kernel, dim3(1), dim3(1024), 0, s, col_total, (int)n_cols, col_ptr);
   ESC_CHECK_LAUNCH("esc_collate_cols.scan");
   return ESC_OK;
 }
@@ -133,8 +132,7 @@ int esc_collate_fill(const esc_collate_args* args, void* stream) {
   ESC_REQUIRE(a.graph_ids && a.offsets && a.node_ptr && a.edge_ptr && a.nnz_ptr && a.y_ptr, "esc_collate_fill: null index arrays");
   ESC_REQUIRE(a.batch && a.edge_index && a.in_ptr && a.out_ptr && a.row_ptr, "esc_collate_fill: null outputs");
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(ESC_K_COLLATE, s);
-  hipLaunchKernelGGL(collate_fill_kernel, dim3((unsigned)a.B, 8), dim3(256), 0, s, a);
+  esc::launch(ESC_K_COLLATE, collate_fill_kernel, dim3((unsigned)a.B, 8), dim3(256), 0, s, a);
   ESC_CHECK_LAUNCH("esc_collate_fill");
   return ESC_OK;
 }

@@ -1,6 +1,7 @@
 // common.h — shared helpers for the gfx950 kernels of libescgnn_hip.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -33,14 +34,21 @@ void set_error(const char* fmt, ...);
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// event-bracket profiler (include/escgnn_hip.h "profiling hook")
-struct ProfScope {
-  int kind;
-  hipStream_t stream;
-  int slot;
-  ProfScope(int kind, hipStream_t s);
-  ~ProfScope();
-};
+// per-launch kernel timing (include/escgnn_hip.h "profiling hook").  When a kernel family is being
+// profiled its launches go through hipExtLaunchKernelGGL with a start/stop event pair, which stamps
+// the dispatch packet itself — the same begin/end a rocprofv3 kernel trace reports — instead of
+// bracketing the launch with stream events (that adds ~3 us of queue latency to a 7 us kernel).
+bool prof_slot(int kind, hipEvent_t* start, hipEvent_t* stop);
+
+template <typename... KArgs, typename... Args>
+inline void launch(int kind, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                   Args... args) {
+  hipEvent_t a = nullptr, b = nullptr;
+  if (prof_slot(kind, &a, &b))
+    hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, a, b, 0, static_cast<KArgs>(args)...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, static_cast<KArgs>(args)...);
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

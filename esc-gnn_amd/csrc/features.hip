@@ -438,11 +438,10 @@ int esc_features_count(const int64_t* node_ptr, const int64_t* edge_ptr, const i
               "esc_features_count: too many nodes+edges in one call");
   hipStream_t s = (hipStream_t)stream;
   WorkLayout w = carve(work, G, total_nodes, total_in_edges);
-  ProfScope prof(ESC_K_FEATURES, s);
-  hipLaunchKernelGGL(feat_prepare_kernel, dim3((unsigned)G), dim3(64), 0, s, node_ptr, edge_ptr, src, dst, (int)G,
+  esc::launch(ESC_K_FEATURES, feat_prepare_kernel, dim3((unsigned)G), dim3(64), 0, s, node_ptr, edge_ptr, src, dst, (int)G,
                      self_loop, w.w_src, w.w_dst, w.w_in, w.e_out, status);
   ESC_CHECK_LAUNCH("esc_features_count.prepare");
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, w.e_out, G, out_edge_ptr);
+  esc::launch(ESC_K_FEATURES, scan_counts_kernel, dim3(1), dim3(1024), 0, s, w.e_out, G, out_edge_ptr);
   ESC_CHECK_LAUNCH("esc_features_count.scan_edges");
   const int64_t cap_edges = total_in_edges + (self_loop ? total_nodes : 0);
   if (cap_edges == 0) {
@@ -461,9 +460,9 @@ int esc_features_count(const int64_t* node_ptr, const int64_t* edge_ptr, const i
   ESC_REQUIRE(lds <= 160 * 1024, "esc_features_count: graph too large for the LDS encoder (%zu B)", lds);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)feat_encode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(feat_encode_kernel<false>, dim3((unsigned)cap_edges), dim3(64), lds, s, a);
+  esc::launch(ESC_K_FEATURES, feat_encode_kernel<false>, dim3((unsigned)cap_edges), dim3(64), lds, s, a);
   ESC_CHECK_LAUNCH("esc_features_count.encode");
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, w.nnz_cnt, cap_edges, nnz_ptr);
+  esc::launch(ESC_K_FEATURES, scan_counts_kernel, dim3(1), dim3(1024), 0, s, w.nnz_cnt, cap_edges, nnz_ptr);
   ESC_CHECK_LAUNCH("esc_features_count.scan_nnz");
   return ESC_OK;
 }
@@ -481,8 +480,7 @@ int esc_features_fill(const int64_t* node_ptr, const int64_t* edge_ptr, int64_t 
   ESC_REQUIRE(out_src && out_dst && pos_enc && pos_index && pos_batch, "esc_features_fill: null output");
   hipStream_t s = (hipStream_t)stream;
   WorkLayout w = carve(work, G, total_nodes, total_in_edges);
-  ProfScope prof(ESC_K_FEATURES, s);
-  hipLaunchKernelGGL(feat_edges_out_kernel, dim3((unsigned)G), dim3(256), 0, s, node_ptr, edge_ptr, w.w_src, w.w_dst,
+  esc::launch(ESC_K_FEATURES, feat_edges_out_kernel, dim3((unsigned)G), dim3(256), 0, s, node_ptr, edge_ptr, w.w_src, w.w_dst,
                      w.w_in, out_edge_ptr, (int)G, out_src, out_dst, in_edge_of_out);
   ESC_CHECK_LAUNCH("esc_features_fill.edges");
   EncodeArgs a{};
@@ -495,7 +493,7 @@ int esc_features_fill(const int64_t* node_ptr, const int64_t* edge_ptr, int64_t 
   ESC_REQUIRE(lds <= 160 * 1024, "esc_features_fill: graph too large for the LDS encoder (%zu B)", lds);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)feat_encode_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(feat_encode_kernel<true>, dim3((unsigned)total_out_edges), dim3(64), lds, s, a);
+  esc::launch(ESC_K_FEATURES, feat_encode_kernel<true>, dim3((unsigned)total_out_edges), dim3(64), lds, s, a);
   ESC_CHECK_LAUNCH("esc_features_fill.encode");
   return ESC_OK;
 }

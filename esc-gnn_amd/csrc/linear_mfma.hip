@@ -27,16 +27,16 @@ namespace esc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
 constexpr int KPAD = 4;
 
-template <int ROWS>
+template <int ROWS, int BK>
 struct KContigTile {            // [ROWS][BK+KPAD]
   static constexpr int LD = BK + KPAD;
   static constexpr int FLOATS = ROWS * LD;
-  static constexpr int PER_THREAD = ROWS * (BK / 4) / 256;  // float4 per thread
+  static constexpr int QPR = BK / 4;                           // float4 per row
+  static constexpr int PER_THREAD = ROWS * QPR / 256;          // float4 per thread
 };
-template <int COLS>
+template <int COLS, int BK>
 struct RedMajorTile {           // [BK][COLS+KPAD]
   static constexpr int LD = COLS + KPAD;
   static constexpr int FLOATS = BK * LD;
@@ -46,28 +46,48 @@ struct RedMajorTile {           // [BK][COLS+KPAD]
 // ---- global -> register staging ------------------------------------------------------------------
 // k-contiguous: rows r0.. of `src` (ld), reduction range [k0, k0+BK); element (r, k) valid iff
 // r < rows && k < kdim.  Optional per-k affine+relu (fused BatchNorm+ReLU of the producer).
-template <int ROWS, bool PRO>
+template <int ROWS, int BK, bool PRO>
 __device__ __forceinline__ void load_kcontig(const float* __restrict__ src, int64_t ld, int r0, int rows,
                                              int k0, int kdim, bool vec_ok,
                                              const float* __restrict__ sc, const float* __restrict__ sh,
-                                             float4 (&reg)[KContigTile<ROWS>::PER_THREAD]) {
+                                             float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
+  using T = KContigTile<ROWS, BK>;
   const int tid = threadIdx.x;
-  const int kq = tid & 7;
+  const int kq = tid % T::QPR;
   const int k = k0 + kq * 4;
+  // Fast path (block-uniform condition): whole 16-B quads inside K.  Loads are UNCONDITIONAL — an
+  // out-of-range row is clamped to the last valid row and zeroed by a select — so hipcc emits straight
+  // global_load_dwordx4 streams instead of a branch + vmcnt(0) per load.
+  if (vec_ok && k0 + BK <= kdim) {
+    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (PRO) {
+      s4 = *reinterpret_cast<const float4*>(sc + k);
+      h4 = *reinterpret_cast<const float4*>(sh + k);
+    }
 #pragma unroll
-  for (int p = 0; p < KContigTile<ROWS>::PER_THREAD; ++p) {
-    const int r = r0 + (tid >> 3) + p * 32;
+    for (int p = 0; p < T::PER_THREAD; ++p) {
+      const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
+      const int rc = min(r, rows - 1);
+      float4 v = *reinterpret_cast<const float4*>(src + (size_t)rc * ld + k);
+      if constexpr (PRO) {
+        v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+      }
+      const bool ok = r < rows;
+      reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < T::PER_THREAD; ++p) {
+    const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < rows) {
       const float* q = src + (size_t)r * ld + k;
-      if (vec_ok && k + 3 < kdim) {
-        v = *reinterpret_cast<const float4*>(q);
-      } else {
-        if (k + 0 < kdim) v.x = q[0];
-        if (k + 1 < kdim) v.y = q[1];
-        if (k + 2 < kdim) v.z = q[2];
-        if (k + 3 < kdim) v.w = q[3];
-      }
+      if (k + 0 < kdim) v.x = q[0];
+      if (k + 1 < kdim) v.y = q[1];
+      if (k + 2 < kdim) v.z = q[2];
+      if (k + 3 < kdim) v.w = q[3];
       if constexpr (PRO) {
         if (k + 0 < kdim) v.x = fmaxf(fmaf(v.x, sc[k + 0], sh[k + 0]), 0.f);
         if (k + 1 < kdim) v.y = fmaxf(fmaf(v.y, sc[k + 1], sh[k + 1]), 0.f);
@@ -78,41 +98,57 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ src, int6
     reg[p] = v;
   }
 }
-template <int ROWS>
-__device__ __forceinline__ void store_kcontig(float* __restrict__ lds, const float4 (&reg)[KContigTile<ROWS>::PER_THREAD]) {
+template <int ROWS, int BK>
+__device__ __forceinline__ void store_kcontig(float* __restrict__ lds, const float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
+  using T = KContigTile<ROWS, BK>;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < KContigTile<ROWS>::PER_THREAD; ++p) {
-    const int r = (tid >> 3) + p * 32;
-    *reinterpret_cast<float4*>(lds + r * KContigTile<ROWS>::LD + (tid & 7) * 4) = reg[p];
+  for (int p = 0; p < T::PER_THREAD; ++p) {
+    const int r = tid / T::QPR + p * (256 / T::QPR);
+    *reinterpret_cast<float4*>(lds + r * T::LD + (tid % T::QPR) * 4) = reg[p];
   }
 }
 
 // reduction-major: rows (reduction) [k0, k0+BK) of `src`, columns c0..c0+COLS; valid iff k < kdim && c < cols.
 // Optional per-COLUMN affine+relu (for act(X) in the weight gradient).
-template <int COLS, bool PRO>
+template <int COLS, int BK, bool PRO>
 __device__ __forceinline__ void load_redmajor(const float* __restrict__ src, int64_t ld, int k0, int kdim,
                                               int c0, int cols, bool vec_ok,
                                               const float* __restrict__ sc, const float* __restrict__ sh,
-                                              float4 (&reg)[RedMajorTile<COLS>::PER_THREAD]) {
+                                              float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;  // float4 per row
+  if (vec_ok && c0 + COLS <= cols) {   // block-uniform fast path: unconditional loads, clamped reduction row
 #pragma unroll
-  for (int p = 0; p < RedMajorTile<COLS>::PER_THREAD; ++p) {
+    for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
+      const int f = tid + p * 256;
+      const int kk = f / QPR, cq = f % QPR;
+      const int k = k0 + kk, c = c0 + cq * 4;
+      const int kc = min(k, kdim - 1);
+      float4 v = *reinterpret_cast<const float4*>(src + (size_t)kc * ld + c);
+      if constexpr (PRO) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sc + c);
+        const float4 h4 = *reinterpret_cast<const float4*>(sh + c);
+        v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+      }
+      const bool ok = k < kdim;
+      reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
     const int f = tid + p * 256;
     const int kk = f / QPR, cq = f % QPR;
     const int k = k0 + kk, c = c0 + cq * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < kdim) {
       const float* q = src + (size_t)k * ld + c;
-      if (vec_ok && c + 3 < cols) {
-        v = *reinterpret_cast<const float4*>(q);
-      } else {
-        if (c + 0 < cols) v.x = q[0];
-        if (c + 1 < cols) v.y = q[1];
-        if (c + 2 < cols) v.z = q[2];
-        if (c + 3 < cols) v.w = q[3];
-      }
+      if (c + 0 < cols) v.x = q[0];
+      if (c + 1 < cols) v.y = q[1];
+      if (c + 2 < cols) v.z = q[2];
+      if (c + 3 < cols) v.w = q[3];
       if constexpr (PRO) {
         if (c + 0 < cols) v.x = fmaxf(fmaf(v.x, sc[c + 0], sh[c + 0]), 0.f);
         if (c + 1 < cols) v.y = fmaxf(fmaf(v.y, sc[c + 1], sh[c + 1]), 0.f);
@@ -123,29 +159,30 @@ __device__ __forceinline__ void load_redmajor(const float* __restrict__ src, int
     reg[p] = v;
   }
 }
-template <int COLS>
-__device__ __forceinline__ void store_redmajor(float* __restrict__ lds, const float4 (&reg)[RedMajorTile<COLS>::PER_THREAD]) {
+template <int COLS, int BK>
+__device__ __forceinline__ void store_redmajor(float* __restrict__ lds, const float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;
 #pragma unroll
-  for (int p = 0; p < RedMajorTile<COLS>::PER_THREAD; ++p) {
+  for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
     const int f = tid + p * 256;
-    *reinterpret_cast<float4*>(lds + (f / QPR) * RedMajorTile<COLS>::LD + (f % QPR) * 4) = reg[p];
+    *reinterpret_cast<float4*>(lds + (f / QPR) * RedMajorTile<COLS, BK>::LD + (f % QPR) * 4) = reg[p];
   }
 }
 
 // ---- fragment reads: 4 consecutive MFMA k-steps of one 32-row block -----------------------------
 // returns f[t] = operand value for MFMA t of 8-chunk `c8` (k = 8*c8 + 4*h + t)
-template <int ROWS>
+template <int ROWS, int BK>
 __device__ __forceinline__ float4 frag_kcontig(const float* __restrict__ lds, int row0, int c8) {
   const int l = lane_id();
-  return *reinterpret_cast<const float4*>(lds + (row0 + (l & 31)) * KContigTile<ROWS>::LD + c8 * 8 + (l >> 5) * 4);
+  return *reinterpret_cast<const float4*>(lds + (row0 + (l & 31)) * KContigTile<ROWS, BK>::LD + c8 * 8 + (l >> 5) * 4);
 }
-template <int COLS>
+template <int COLS, int BK>
 __device__ __forceinline__ float4 frag_redmajor(const float* __restrict__ lds, int col0, int c8) {
   const int l = lane_id();
-  const float* p = lds + (c8 * 8 + (l >> 5) * 4) * RedMajorTile<COLS>::LD + col0 + (l & 31);
-  return make_float4(p[0], p[RedMajorTile<COLS>::LD], p[2 * RedMajorTile<COLS>::LD], p[3 * RedMajorTile<COLS>::LD]);
+  constexpr int LD = RedMajorTile<COLS, BK>::LD;
+  const float* p = lds + (c8 * 8 + (l >> 5) * 4) * LD + col0 + (l & 31);
+  return make_float4(p[0], p[LD], p[2 * LD], p[3 * LD]);
 }
 
 // =================================================================================================
@@ -168,16 +205,16 @@ struct GemmArgs {
   int a_vec, b_vec, c_slab; // alignment flags; c_slab: C is a [splits][rowsC][colsC] slab buffer
 };
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool PRO, bool DB>
+template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NT = TN / 32;
   static_assert(MT >= 1 && NT >= 1, "wave tile must hold at least one 32x32 block");
-  using ATile = typename std::conditional<A_KC, KContigTile<BM>, RedMajorTile<BM>>::type;
-  using BTile = typename std::conditional<B_KC, KContigTile<BN>, RedMajorTile<BN>>::type;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (ATile::FLOATS + BTile::FLOATS)];
+  using ATile = typename std::conditional<A_KC, KContigTile<BM, BK>, RedMajorTile<BM, BK>>::type;
+  using BTile = typename std::conditional<B_KC, KContigTile<BN, BK>, RedMajorTile<BN, BK>>::type;
   constexpr int STAGE = ATile::FLOATS + BTile::FLOATS;   // one K-step of A then B
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 stages
 
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
@@ -196,32 +233,24 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[ATile::PER_THREAD];
-  float4 rb[BTile::PER_THREAD];
+  // two register sets: tile kt+1 waits in one while tile kt+2 is being fetched into the other
+  float4 ra0[ATile::PER_THREAD], rb0[BTile::PER_THREAD];
+  float4 ra1[ATile::PER_THREAD], rb1[BTile::PER_THREAD];
   float dbsum = 0.f;
 
-  auto gload = [&](int k0) {
-    if constexpr (A_KC) load_kcontig<BM, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
-    else                load_redmajor<BM, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
-    if constexpr (B_KC) load_kcontig<BN, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
-    else                load_redmajor<BN, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
+  auto gload = [&](int k0, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD]) {
+    if constexpr (A_KC) load_kcontig<BM, BK, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
+    else                load_redmajor<BM, BK, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
+    if constexpr (B_KC) load_kcontig<BN, BK, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
+    else                load_redmajor<BN, BK, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const float4 (&ra)[ATile::PER_THREAD], const float4 (&rb)[BTile::PER_THREAD]) {
     float* a_w = lds + buf * STAGE;
     float* b_w = a_w + ATile::FLOATS;
-    if constexpr (A_KC) store_kcontig<BM>(a_w, ra); else store_redmajor<BM>(a_w, ra);
-    if constexpr (B_KC) store_kcontig<BN>(b_w, rb); else store_redmajor<BN>(b_w, rb);
+    if constexpr (A_KC) store_kcontig<BM, BK>(a_w, ra); else store_redmajor<BM, BK>(a_w, ra);
+    if constexpr (B_KC) store_kcontig<BN, BK>(b_w, rb); else store_redmajor<BN, BK>(b_w, rb);
   };
-
-  const int nk = (red1 > red0) ? (red1 - red0 + BK - 1) / BK : 0;
-  if (nk > 0) {
-    gload(red0);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(red0 + (kt + 1) * BK);
+  auto compute = [&](int cur) {
     const float* a_l = lds + cur * STAGE;
     const float* b_l = a_l + ATile::FLOATS;
     if constexpr (DB) {   // column sums of the reduction-major A' tile (bias gradient), block column 0 only
@@ -235,13 +264,13 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
       float4 af[MT], bf[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        if constexpr (A_KC) af[i] = frag_kcontig<BM>(a_l, wm * TM + i * 32, c8);
-        else                af[i] = frag_redmajor<BM>(a_l, wm * TM + i * 32, c8);
+        if constexpr (A_KC) af[i] = frag_kcontig<BM, BK>(a_l, wm * TM + i * 32, c8);
+        else                af[i] = frag_redmajor<BM, BK>(a_l, wm * TM + i * 32, c8);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if constexpr (B_KC) bf[j] = frag_kcontig<BN>(b_l, wn * TN + j * 32, c8);
-        else                bf[j] = frag_redmajor<BN>(b_l, wn * TN + j * 32, c8);
+        if constexpr (B_KC) bf[j] = frag_kcontig<BN, BK>(b_l, wn * TN + j * 32, c8);
+        else                bf[j] = frag_redmajor<BN, BK>(b_l, wn * TN + j * 32, c8);
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -253,7 +282,23 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+  };
+
+  const int nk = (red1 > red0) ? (red1 - red0 + BK - 1) / BK : 0;
+  if (nk > 0) gload(red0, ra0, rb0);
+  if (nk > 1) gload(red0 + BK, ra1, rb1);
+  if (nk > 0) lstore(0, ra0, rb0);
+  __syncthreads();
+  // invariant at the top of iteration kt: LDS[kt&1] = tile kt; register set (kt+1)&1 = tile kt+1 (in flight)
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) gload(red0 + (kt + 2) * BK, ra0, rb0);
+    compute(0);
+    if (kt + 1 < nk) lstore(1, ra1, rb1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) gload(red0 + (kt + 3) * BK, ra1, rb1);
+    compute(1);
+    if (kt + 2 < nk) lstore(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -293,19 +338,60 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   out[(i / cols) * ld_out + (i % cols)] = s;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool PRO, bool DB>
+template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
 static void launch_tile(const GemmArgs& g, int splits, hipStream_t s) {
+  using ATile = typename std::conditional<A_KC, KContigTile<BM, BK>, RedMajorTile<BM, BK>>::type;
+  using BTile = typename std::conditional<B_KC, KContigTile<BN, BK>, RedMajorTile<BN, BK>>::type;
+  constexpr size_t lds = 2 * (ATile::FLOATS + BTile::FLOATS) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+  auto kern = gemm_tile_kernel<BM, BN, WM, WN, BK, A_KC, B_KC, PRO, DB>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;          // per instantiation
+    if (!raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
+  }
   dim3 grid((unsigned)cdiv(g.colsC, BN), (unsigned)cdiv(g.rowsC, BM), (unsigned)splits);
-  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, A_KC, B_KC, PRO, DB>), grid, dim3(256), 0, s, g);
+  esc::launch(ESC_K_LINEAR, kern, grid, dim3(256), lds, s, g);
+}
+
+// tile shapes, selectable per call site (esc_tune_set) — ids are stable
+//   0: 128x128 BK32   1: 64x64 BK32   2: 128x32 BK32 (narrow outputs)   3: 128x64 BK32   4: 64x64 BK64
+#define ESC_TILE_DISPATCH(ID, AKC, BKC, PRO, DB)                                                     \
+  switch (ID) {                                                                                      \
+    case 0: launch_tile<128, 128, 2, 2, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                 \
+    case 2: launch_tile<128, 32, 4, 1, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                  \
+    case 3: launch_tile<128, 64, 2, 2, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                  \
+    case 4: launch_tile<64, 64, 2, 2, 64, AKC, BKC, PRO, DB>(g, splits, s); break;                   \
+    default: launch_tile<64, 64, 2, 2, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                  \
+  }
+
+static void tile_dims(int id, int* bm, int* bn, int* bk) {
+  switch (id) {
+    case 0: *bm = 128; *bn = 128; *bk = 32; break;
+    case 2: *bm = 128; *bn = 32; *bk = 32; break;
+    case 3: *bm = 128; *bn = 64; *bk = 32; break;
+    case 4: *bm = 64; *bn = 64; *bk = 64; break;
+    default: *bm = 64; *bn = 64; *bk = 32; break;
+  }
 }
 
 static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (ld % 4 == 0); }
+
+// tuning knobs (esc_tune_set): defaults chosen from scratch/gemm_bench.py sweeps on MI355X
+enum { KNOB_FWD_BIG = 0, KNOB_FWD_SMALL = 1, KNOB_DX_BIG = 2, KNOB_DX_SMALL = 3, KNOB_DW_TILE = 4,
+       KNOB_DW_BLOCKS = 5, KNOB_COUNT = 6 };
+static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512};
 
 }  // namespace esc
 
 using namespace esc;
 
 extern "C" {
+
+int esc_tune_set(int knob, int value) {
+  ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
+  g_knob[knob] = value;
+  return ESC_OK;
+}
 
 int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
                    const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
@@ -322,18 +408,10 @@ int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, c
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.db_part = nullptr;
   g.rowsC = (int)M; g.colsC = (int)N; g.red = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
   g.a_vec = vec_ok(X, ld_x); g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
-  ProfScope prof(ESC_K_LINEAR, s);
-  const bool pro = in_scale != nullptr;
-  if (N <= 32) {
-    if (pro) launch_tile<128, 32, 4, 1, true, true, true, false>(g, 1, s);
-    else     launch_tile<128, 32, 4, 1, true, true, false, false>(g, 1, s);
-  } else if (M >= 8192) {
-    if (pro) launch_tile<128, 128, 2, 2, true, true, true, false>(g, 1, s);
-    else     launch_tile<128, 128, 2, 2, true, true, false, false>(g, 1, s);
-  } else {
-    if (pro) launch_tile<64, 64, 2, 2, true, true, true, false>(g, 1, s);
-    else     launch_tile<64, 64, 2, 2, true, true, false, false>(g, 1, s);
-  }
+  const int splits = 1;
+  const int id = (N <= 32) ? 2 : (M >= 8192 ? g_knob[KNOB_FWD_BIG] : g_knob[KNOB_FWD_SMALL]);
+  if (in_scale) { ESC_TILE_DISPATCH(id, true, true, true, false) }
+  else          { ESC_TILE_DISPATCH(id, true, true, false, false) }
   ESC_CHECK_LAUNCH("esc_linear_fwd");
   return ESC_OK;
 }
@@ -350,22 +428,24 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
   g.A = dY; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.C = dX; g.ldc = ld_dx; g.bias = nullptr;
   g.rowsC = (int)M; g.colsC = (int)K; g.red = (int)N; g.red_per_split = (int)N; g.accumulate = accumulate;
   g.a_vec = vec_ok(dY, ld_dy); g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
-  ProfScope prof(ESC_K_LINEAR, s);
-  if (K <= 32)        launch_tile<128, 32, 4, 1, true, false, false, false>(g, 1, s);
-  else if (M >= 8192) launch_tile<128, 128, 2, 2, true, false, false, false>(g, 1, s);
-  else                launch_tile<64, 64, 2, 2, true, false, false, false>(g, 1, s);
+  const int splits = 1;
+  const int id = (K <= 32) ? 2 : (M >= 8192 ? g_knob[KNOB_DX_BIG] : g_knob[KNOB_DX_SMALL]);
+  ESC_TILE_DISPATCH(id, true, false, false, false)
   ESC_CHECK_LAUNCH("esc_linear_bwd_input");
   return ESC_OK;
 }
 
 static void wgrad_plan(int64_t M, int64_t N, int64_t K, int* splits, int* per_split) {
-  // 64x64 output tiles; enough splits along M for >= ~512 workgroups, each >= 128 rows deep
-  const int64_t tiles = cdiv(N, 64) * cdiv(K, 64);
-  int64_t want = cdiv(512, tiles);
+  // enough splits along M for ~KNOB_DW_BLOCKS workgroups, each >= 128 rows deep (fixed by the shape
+  // only, so scratch sizing and the launch agree)
+  int bm, bn, bk;
+  tile_dims(g_knob[KNOB_DW_TILE], &bm, &bn, &bk);
+  const int64_t tiles = cdiv(N, bm) * cdiv(K, bn);
+  int64_t want = cdiv(g_knob[KNOB_DW_BLOCKS], tiles);
   int64_t max_splits = cdiv(M, 128);
   int64_t sp = want < 1 ? 1 : (want > max_splits ? max_splits : want);
   if (sp < 1) sp = 1;
-  int64_t per = cdiv(cdiv(M, sp), BK) * BK;
+  int64_t per = cdiv(cdiv(M, sp), bk) * bk;
   sp = cdiv(M, per);
   if (sp < 1) sp = 1;
   *splits = (int)sp;
@@ -373,9 +453,8 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t K, int* splits, int* per_sp
 }
 
 int64_t esc_linear_bwd_weight_scratch(int64_t M, int64_t N, int64_t K) {
-  int sp, per;
-  wgrad_plan(M, N, K, &sp, &per);
-  return (int64_t)sp * (N * K + N);
+  // upper bound over every tunable plan: at most ceil(M/128) splits
+  return (cdiv(M, 128) + 1) * (N * K + N);
 }
 
 int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x,
@@ -387,23 +466,23 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
   ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_bwd_weight: in_scale/in_shift must come together");
   ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_weight: dimension too large");
   hipStream_t s = (hipStream_t)stream;
-  int sp, per;
-  wgrad_plan(M, N, K, &sp, &per);
+  int splits, per;
+  wgrad_plan(M, N, K, &splits, &per);
   GemmArgs g{};
   g.A = dY; g.lda = ld_dy; g.B = X; g.ldb = ld_x; g.C = slabs; g.ldc = K; g.bias = nullptr;
   g.pro_scale = in_scale; g.pro_shift = in_shift;
-  g.db_part = slabs + (size_t)sp * N * K;
+  g.db_part = slabs + (size_t)splits * N * K;
   g.rowsC = (int)N; g.colsC = (int)K; g.red = (int)M; g.red_per_split = per; g.accumulate = 0;
   g.a_vec = vec_ok(dY, ld_dy); g.b_vec = vec_ok(X, ld_x); g.c_slab = 1;
-  ProfScope prof(ESC_K_LINEAR, s);
-  if (in_scale) launch_tile<64, 64, 2, 2, false, false, true, true>(g, sp, s);
-  else          launch_tile<64, 64, 2, 2, false, false, false, true>(g, sp, s);
+  const int id = g_knob[KNOB_DW_TILE];
+  if (in_scale) { ESC_TILE_DISPATCH(id, false, false, true, true) }
+  else          { ESC_TILE_DISPATCH(id, false, false, false, true) }
   ESC_CHECK_LAUNCH("esc_linear_bwd_weight.tiles");
   const int64_t n = N * K;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, slabs, n, sp, (int)K, dW, ld_dw);
+  esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, slabs, n, splits, (int)K, dW, ld_dw);
   ESC_CHECK_LAUNCH("esc_linear_bwd_weight.reduce");
   if (db) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, g.db_part, N, sp, (int)N, db, N);
+    esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, g.db_part, N, splits, (int)N, db, N);
     ESC_CHECK_LAUNCH("esc_linear_bwd_weight.bias");
   }
   return ESC_OK;

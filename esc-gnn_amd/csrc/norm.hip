@@ -38,28 +38,45 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   partial[(size_t)slot * C + c] = out;
 }
 
+// Chan/Welford merge of two (count, mean, M2) partials
+__device__ __forceinline__ void chan_merge(double& n, double& mu, double& m2, double nb, double mub, double m2b) {
+  if (nb == 0.0) return;
+  const double tot = n + nb;
+  const double delta = mub - mu;
+  mu += delta * nb / tot;
+  m2 += m2b + delta * delta * n * nb / tot;
+  n = tot;
+}
+
+// one wave per column: lanes own slots lane, lane+64, ... then a shuffle-tree merge (fixed order)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restrict__ partial, int M, int C, int P,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ invstd,
                                                           float* __restrict__ running_mean,
                                                           float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (c >= C) return;
+  const int lane = lane_id();
   double n = 0.0, mu = 0.0, m2 = 0.0;
-  for (int p = 0; p < P && p < M; ++p) {
-    const double np = (double)((M - p + P - 1) / P);       // rows owned by slot p
+  for (int p = lane; p < P && p < M; p += 64) {
     const float2 v = partial[(size_t)p * C + c];
-    const double delta = (double)v.x - mu;
-    const double tot = n + np;
-    mu += delta * np / tot;
-    m2 += (double)v.y + delta * delta * n * np / tot;
-    n = tot;
+    chan_merge(n, mu, m2, (double)((M - p + P - 1) / P), (double)v.x, (double)v.y);
   }
-  const double var = m2 / (double)M;
-  mean[c] = (float)mu;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (double)(M - 1));
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double nb = __shfl_xor(n, o, 64), mub = __shfl_xor(mu, o, 64), m2b = __shfl_xor(m2, o, 64);
+    // merge the higher lane into the lower one in both partners identically (commutative up to rounding:
+    // order the pair by lane parity so both compute the same expression)
+    if ((lane & o) == 0) chan_merge(n, mu, m2, nb, mub, m2b);
+    else { double n2 = nb, mu2 = mub, m22 = m2b; chan_merge(n2, mu2, m22, n, mu, m2); n = n2; mu = mu2; m2 = m22; }
+  }
+  if (lane == 0) {
+    const double var = m2 / (double)M;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (double)(M - 1));
+  }
 }
 
 template <int VEC>
@@ -123,17 +140,22 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __re
                                                               int P, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta,
                                                               float2* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // one wave per column
   if (c >= C) return;
+  const int lane = lane_id();
   double s1 = 0.0, s2 = 0.0;
-  for (int p = 0; p < P; ++p) {
+  for (int p = lane; p < P; p += 64) {
     const float2 v = partial[(size_t)p * C + c];
     s1 += (double)v.x;
     s2 += (double)v.y;
   }
-  if (dgamma) dgamma[c] = (float)s2;
-  if (dbeta) dbeta[c] = (float)s1;
-  coef[c] = make_float2((float)(s1 / M), (float)(s2 / M));
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    coef[c] = make_float2((float)(s1 / M), (float)(s2 / M));
+  }
 }
 
 template <int VEC>
@@ -198,10 +220,9 @@ int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, 
   ESC_REQUIRE(M > 1 && C > 0 && ld_x >= C && M < (1LL << 31), "esc_bn_stats: need more than 1 row per channel (M=%ld, C=%ld)", (long)M, (long)C);
   hipStream_t s = (hipStream_t)stream;
   const int rb = rowblocks(M);
-  ProfScope prof(ESC_K_NORM, s);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
+  esc::launch(ESC_K_NORM, bn_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
   ESC_CHECK_LAUNCH("esc_bn_stats.partial");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, eps, momentum, mean, invstd, running_mean, running_var);
+  esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, eps, momentum, mean, invstd, running_mean, running_var);
   ESC_CHECK_LAUNCH("esc_bn_stats.finalize");
   return ESC_OK;
 }
@@ -216,9 +237,8 @@ int esc_bn_apply(const float* X, int64_t ld_x, int64_t M, int64_t C, const float
   const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && aligned16(X) && aligned16(Y);
   const int64_t work = M * (vec ? C / 4 : C);
   const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
-  ProfScope prof(ESC_K_NORM, s);
-  if (vec) hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, mean, invstd, gamma, beta, relu, Y, ld_y);
-  else     hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, mean, invstd, gamma, beta, relu, Y, ld_y);
+  if (vec) esc::launch(ESC_K_NORM, bn_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, mean, invstd, gamma, beta, relu, Y, ld_y);
+  else     esc::launch(ESC_K_NORM, bn_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, mean, invstd, gamma, beta, relu, Y, ld_y);
   ESC_CHECK_LAUNCH("esc_bn_apply");
   return ESC_OK;
 }
@@ -233,17 +253,16 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   const int rb = rowblocks(M);
   float2* partial = (float2*)scratch;
   float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
-  ProfScope prof(ESC_K_NORM, s);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, partial);
+  esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, partial);
   ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
+  esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
   ESC_CHECK_LAUNCH("esc_bn_bwd.finalize");
   const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) && (!relu || ld_y % 4 == 0) &&
                    aligned16(X) && aligned16(dY) && aligned16(dX) && (!relu || aligned16(Y));
   const int64_t work = M * (vec ? C / 4 : C);
   const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
-  if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
-  else     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
+  if (vec) esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
+  else     esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
   ESC_CHECK_LAUNCH("esc_bn_bwd.apply");
   return ESC_OK;
 }

@@ -55,7 +55,7 @@ int esc_l1_loss(const float* pred, const float* y, int64_t M, int64_t denom, flo
                 float* dpred, void* stream) {
   ESC_REQUIRE(pred && y && loss, "esc_l1_loss: null pointer");
   ESC_REQUIRE(M > 0 && denom > 0, "esc_l1_loss: empty batch");
-  hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, y, M, (double)denom, grad_scale, loss, dpred);
+  esc::launch(-1, l1_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, y, M, (double)denom, grad_scale, loss, dpred);
   ESC_CHECK_LAUNCH("esc_l1_loss");
   return ESC_OK;
 }
@@ -68,7 +68,7 @@ int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const unsigned blocks = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+  esc::launch(-1, adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                      (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
                      (float)(-lr / bc1));
   ESC_CHECK_LAUNCH("esc_adam_step");

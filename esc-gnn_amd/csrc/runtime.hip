@@ -23,23 +23,20 @@ struct ProfState {
 static ProfState g_prof[ESC_K_COUNT];
 static std::mutex g_prof_mu;
 
-ProfScope::ProfScope(int k, hipStream_t s) : kind(k), stream(s), slot(-1) {
-  if (k < 0 || k >= ESC_K_COUNT || !g_prof[k].on) return;
+bool prof_slot(int k, hipEvent_t* start, hipEvent_t* stop) {
+  if (k < 0 || k >= ESC_K_COUNT || !g_prof[k].on) return false;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfState& p = g_prof[k];
   if (p.used == p.start.size()) {
     hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
     p.start.push_back(a);
     p.stop.push_back(b);
   }
-  slot = (int)p.used++;
-  (void)hipEventRecord(p.start[slot], stream);
-}
-
-ProfScope::~ProfScope() {
-  if (slot < 0) return;
-  (void)hipEventRecord(g_prof[kind].stop[slot], stream);
+  *start = p.start[p.used];
+  *stop = p.stop[p.used];
+  ++p.used;
+  return true;
 }
 
 }  // namespace esc
