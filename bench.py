@@ -94,9 +94,7 @@ def main():
 
     model = E.NestedGIN_eff(None, args.layers, args.hidden, use_rd=True, graph_pred=False, dropout=0,
                             edge_nest=True, use_cycle=True).to(dev)
-    if world > 1:                                           # identical replicas
-        for p in model.parameters():
-            dist.broadcast(p.data, 0)
+    E.parallel.broadcast_parameters(model, 0)               # identical replicas
     opt = E.optim.FlatAdam(model.parameters(), lr=args.lr)
     model.train()
 
@@ -108,9 +106,8 @@ def main():
         pred = model(b)
         loss = E.ops.l1_loss(pred, b.y)
         loss.backward()
-        if world > 1:
-            dist.all_reduce(opt.flat_grad)
-            opt.flat_grad.div_(world)
+        if world > 1:                                       # ONE RCCL all-reduce: grad*n_local ++ [n_local]
+            opt.all_reduce_weighted(b.x.size(0))
         opt.step()
         if count:
             stats["graphs"] += args.batch_size

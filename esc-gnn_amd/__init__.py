@@ -8,7 +8,7 @@ from .data import Data  # noqa: F401
 from .batch import Batch  # noqa: F401
 from .dataloader import DataLoader  # noqa: F401
 from .plan import BatchPlan, plan_of  # noqa: F401
-from . import _native, ops, optim  # noqa: F401
+from . import _native, ops, optim, parallel  # noqa: F401
 from .nn import GINEConv, Linear, global_add_pool, global_mean_pool  # noqa: F401
 from .run_graphcount import NestedGIN_eff  # noqa: F401
 from .store import DeviceGraphStore, DeviceLoader  # noqa: F401

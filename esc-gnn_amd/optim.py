@@ -6,45 +6,19 @@ exchange is one RCCL all-reduce of `flat_grad`.  Arithmetic =
 import torch
 
 from . import _native as nv
+from .parallel import FlatBucket
 
 
-class FlatAdam(object):
+class FlatAdam(FlatBucket):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        self.params = [p for p in params]
-        if not self.params:
-            raise ValueError("FlatAdam: no parameters")
-        dev = self.params[0].device
-        if dev.type != "cuda":
+        params = [p for p in params]
+        if params and params[0].device.type != "cuda":
             raise RuntimeError("FlatAdam runs on the HIP device only; there is no CPU fallback")
-        n = sum(p.numel() for p in self.params)
-        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            k = p.numel()
-            self.flat_param[off:off + k].copy_(p.data.reshape(-1))
-            p.data = self.flat_param[off:off + k].view(p.shape)
-            p.grad = self.flat_grad[off:off + k].view(p.shape)
-            off += k
+        super().__init__(params)
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, params=self.params)]
         self.step_count = 0
-
-    def zero_grad(self, set_to_none=False):
-        """Gradients are persistent views of flat_grad: zero in place (autograd then accumulates into them)."""
-        self.flat_grad.zero_()
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr():
-                self._rebind()
-                break
-
-    def _rebind(self):
-        off = 0
-        for p in self.params:
-            k = p.numel()
-            p.grad = self.flat_grad[off:off + k].view(p.shape)
-            off += k
 
     def step(self):
         g = self.param_groups[0]
@@ -63,3 +37,27 @@ class FlatAdam(object):
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
+
+
+class ReduceLROnPlateau(object):
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold=1e-4 rel) as configured at
+    reference run_graphcount.py:479-480 (factor=lr_decay_factor, patience, min_lr=1e-5); works on any
+    object with `param_groups`."""
+
+    def __init__(self, optimizer, mode="min", factor=0.1, patience=10, min_lr=0.0, threshold=1e-4):
+        assert mode == "min"
+        self.optimizer, self.factor, self.patience, self.min_lr, self.threshold = optimizer, factor, patience, min_lr, threshold
+        self.best, self.num_bad = float("inf"), 0
+
+    def step(self, metric):
+        m = float(metric)
+        if m < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad = m, 0
+        else:
+            self.num_bad += 1
+        if self.num_bad > self.patience:
+            for g in self.optimizer.param_groups:
+                new = max(g["lr"] * self.factor, self.min_lr)
+                if g["lr"] - new > 1e-8:
+                    g["lr"] = new
+            self.num_bad = 0

@@ -1,0 +1,76 @@
+"""Graph-sharded data parallelism for NestedGIN_eff.
+
+The reference has no distributed path (its only hook, kernel/train_eval.py:44-58, is never
+initialised).  Graphs are independent, so a global batch is sharded BY GRAPH: rank r of W takes the
+contiguous slice [r*B/W, (r+1)*B/W) (concatenating rank outputs reproduces single-device order), runs
+the hot path on its shard with no data-path collective, and the step ends with ONE all-reduce of the
+flat fp32 gradient bucket (RCCL over xGMI on MI355X; gloo in the CPU tests).
+
+Exact global-mean loss: the reference's L1Loss averages over all N nodes of the batch.  Each rank
+back-propagates its LOCAL mean; the bucket carries `grad * n_local` plus one extra slot holding
+`n_local`, so after a single SUM all-reduce `bucket[:-1] / bucket[-1]` is the gradient of
+sum_r sum_i |err| / N_global — no second collective for the denominator.
+
+BatchNorm uses each shard's own batch statistics (plain DP).  Matching the single-device statistics
+would need a (sum, sumsq, count) all-reduce per BN layer (SyncBN) — not enabled in this revision.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_slice(batch_size, rank, world):
+    """Contiguous graph slice of rank `rank` (sizes differ by at most one)."""
+    base, rem = divmod(batch_size, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatBucket(object):
+    """Re-homes parameters and gradients of a model as views into two flat fp32 buffers
+    (+1 trailing slot in the gradient buffer for the node-count piggyback)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatBucket: no parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.numel = n
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self._grad_store = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.flat_grad = self._grad_store[:n]
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat_param[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + k].view(p.shape)
+            p.grad = self.flat_grad[off:off + k].view(p.shape)
+            off += k
+
+    def zero_grad(self, set_to_none=False):
+        self._grad_store.zero_()
+        off = 0
+        for p in self.params:                     # autograd may have replaced .grad: re-bind the views
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad[off:off + k].data_ptr():
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+            off += k
+
+    def all_reduce_weighted(self, n_local, group=None):
+        """grad <- sum_r n_r * grad_r / sum_r n_r   with one SUM all-reduce."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return float(n_local)
+        self.flat_grad.mul_(float(n_local))
+        self._grad_store[-1] = float(n_local)
+        dist.all_reduce(self._grad_store, op=dist.ReduceOp.SUM, group=group)
+        total = self._grad_store[-1:].clone()
+        self.flat_grad.div_(total)
+        return total
+
+
+def broadcast_parameters(model, src=0, group=None):
+    """Identical replicas at start (parameters and BN buffers)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src, group=group)

@@ -83,3 +83,215 @@ class NestedGIN_eff(torch.nn.Module):
         if not self.use_cycle:
             o = F.log_softmax(o, dim=-1)
         return (o, cat) if return_embeddings else o
+
+
+# =====================================================================================================
+# Training harness — `python -m esc_gnn_amd.run_graphcount ...` (flags of reference :315-358)
+# =====================================================================================================
+_FLAGS = [  # (name, kwargs) — same names, types and defaults as the reference CLI
+    ("--model", dict(default="NestedGIN_eff", type=str, help="NestedGIN_eff (PPGN_eff: dense 3-WL baseline, out of scope)")),
+    ("--target", dict(default=3, type=int)),
+    ("--ab", dict(action="store_true", default=False)),
+    ("--layers", dict(type=int, default=5)),
+    ("--h", dict(type=int, default=3, help="hop of enclosing subgraph")),
+    ("--max_nodes_per_hop", dict(type=int, default=None)),
+    ("--node_label", dict(type=str, default="hop")),
+    ("--epochs", dict(type=int, default=2000)),
+    ("--batch_size", dict(type=int, default=256)),
+    ("--lr", dict(type=float, default=1e-3)),
+    ("--lr_decay_factor", dict(type=float, default=0.9)),
+    ("--patience", dict(type=int, default=10)),
+    ("--normalize_x", dict(action="store_true", default=False)),
+    ("--not_normalize_dist", dict(action="store_true", default=False)),
+    ("--RNI", dict(action="store_true", default=False)),
+    ("--use_relative_pos", dict(action="store_true", default=False)),
+    ("--seed", dict(type=int, default=0)),
+    ("--save_appendix", dict(default="")),
+    ("--keep_old", dict(action="store_true", default=False)),
+    ("--dataset", dict(default="count_cycle", help="count_cycle/count_graphlet")),
+    ("--load_model", dict(default=None)),
+    ("--eval", dict(default=0, type=int)),
+    ("--train_only", dict(default=0, type=int)),
+    # additions (not in the reference): synthetic data when data/<dataset>/raw/data.mat is absent
+    ("--synthetic_graphs", dict(type=int, default=5000, help="size of the synthetic count_cycle-shaped dataset")),
+    ("--data_root", dict(default="data")),
+]
+
+
+def build_parser():
+    import argparse
+    ap = argparse.ArgumentParser(description="NestedGNN for counting experiments (MI355X hot path).")
+    for name, kw in _FLAGS:
+        ap.add_argument(name, **kw)
+    return ap
+
+
+def _load_splits(args):
+    """train/val/test lists of pre-transformed Data (reference :404-430)."""
+    import os
+    from .datasets import build_count_dataset, load_count_mat
+    from .utils_edge_efficient import create_subgraphs_many
+    mat = os.path.join(args.data_root, args.dataset, "raw", "data.mat")
+    if os.path.exists(mat):
+        splits = []
+        for name in ("train", "val", "test"):
+            raw = load_count_mat(mat, name)
+            splits.append(create_subgraphs_many(raw, args.h, use_rd=True, self_loop=True))
+        return splits, True
+    G = args.synthetic_graphs
+    n_tr, n_val = int(0.3 * G), int(0.2 * G)              # 30/20/50 split by index (SURVEY §8d)
+    alld = build_count_dataset(0, G, h=args.h, use_rd=True, self_loop=True)
+    return [alld[:n_tr], alld[n_tr:n_tr + n_val], alld[n_tr + n_val:]], False
+
+
+def main(argv=None):
+    import os
+    import random
+    import shutil
+    import sys
+    import time
+
+    import numpy as np
+    import torch.distributed as dist
+
+    from . import ops
+    from .optim import FlatAdam, ReduceLROnPlateau
+    from .parallel import broadcast_parameters, shard_slice
+    from .store import DeviceGraphStore
+
+    args = build_parser().parse_args(argv)
+    if args.model != "NestedGIN_eff":
+        print("Model not implemented")
+        raise NotImplementedError
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("run_graphcount: needs a HIP device (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    torch.manual_seed(args.seed)                          # reference :361-366
+    torch.cuda.manual_seed_all(args.seed)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+
+    if args.save_appendix == "":
+        args.save_appendix = "_" + time.strftime("%Y%m%d%H%M%S")
+    args.res_dir = "results/" + args.dataset + "_" + args.save_appendix
+    cmd_input = "python " + " ".join(sys.argv) + "\n"
+    if rank == 0:
+        print("Results will be saved in " + args.res_dir)
+        os.makedirs(args.res_dir, exist_ok=True)
+        here = os.path.dirname(os.path.abspath(__file__))
+        for f in ("run_graphcount.py", "utils_edge_efficient.py"):     # reference :381-383 backs its sources up
+            shutil.copy(os.path.join(here, f), args.res_dir)
+        with open(os.path.join(args.res_dir, "cmd_input.txt"), "a") as fh:
+            fh.write(cmd_input)
+        print("Command line input: " + cmd_input + " is saved.")
+    target = int(args.target)
+    if rank == 0:
+        print("---- Target: {} ----".format(target))
+
+    (tr, va, te), real = _load_splits(args)
+
+    def column(d):                                        # MyTransform (reference :35-37)
+        y = d.y
+        return y[:, target] if (real and y.dim() == 2) else y.reshape(-1)
+    for part in (tr, va, te):
+        for d in part:
+            d.y = column(d).float()
+    y_train_val = torch.cat([d.y for d in tr + va])       # reference :441-447
+    mean, std = y_train_val.mean(), y_train_val.std()
+    for part in (tr, va, te):
+        for d in part:
+            d.y = (d.y - mean) / std
+    if rank == 0:
+        print("Mean = %.3f, Std = %.3f" % (float(mean), float(std)))
+    stores = [DeviceGraphStore(part, device) for part in (tr, va, te)]
+    n_train_targets = sum(d.y.numel() for d in tr)
+
+    model = NestedGIN_eff(None, args.layers, 256, use_rd=True, graph_pred=False, dropout=0, edge_nest=True,
+                          use_cycle=True)                # reference :465
+    if args.load_model is not None:
+        model.load_state_dict(torch.load(args.load_model, map_location="cpu"))
+    if rank == 0:
+        print("Using " + model.__class__.__name__ + " model")
+    model = model.to(device)
+    broadcast_parameters(model, 0)
+    optimizer = FlatAdam(model.parameters(), lr=args.lr)
+    scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=args.lr_decay_factor, patience=args.patience,
+                                  min_lr=0.00001)
+    gen = torch.Generator().manual_seed(args.seed)
+
+    def batches(store, shuffle):
+        G = len(store)
+        order = torch.randperm(G, generator=gen) if shuffle else torch.arange(G)
+        for i in range(0, G, args.batch_size):
+            ids = order[i:i + args.batch_size]
+            lo, hi = shard_slice(ids.numel(), rank, world)           # shard the global batch by graph
+            if hi > lo:
+                yield store.collate(ids[lo:hi])
+
+    def train(epoch):
+        model.train()
+        loss_all = torch.zeros((), device=device)
+        for data in batches(stores[0], True):
+            optimizer.zero_grad()
+            loss = ops.l1_loss(model(data), data.y.view(-1, 1))
+            loss.backward()
+            n_glob = optimizer.all_reduce_weighted(data.y.size(0)) if world > 1 else data.y.size(0)
+            loss_all += loss.detach() * data.y.size(0)
+            optimizer.step()
+        if world > 1:
+            dist.all_reduce(loss_all)
+        return float(loss_all) / n_train_targets
+
+    def test(store):
+        model.eval()
+        err, num = torch.zeros((), device=device), 0
+        with torch.no_grad():
+            for data in batches(store, False):
+                y_hat = model(data)[:, 0]
+                err += torch.sum(torch.abs(y_hat - data.y))
+                num += data.y.size(0)
+        tot = torch.stack([err, torch.tensor(float(num), device=device)])
+        if world > 1:
+            dist.all_reduce(tot)
+        return float(tot[0] / tot[1]) * float(std)
+
+    if args.eval:
+        print("Test MAE: %.7f" % test(stores[2]))
+        return
+    best_val_error, count, log = None, 0, ""
+    for epoch in range(1, args.epochs + 1):
+        lr = optimizer.param_groups[0]["lr"]
+        loss = train(epoch)
+        val_error = test(stores[1])
+        scheduler.step(val_error)
+        count += 1
+        if best_val_error is None:
+            best_val_error = val_error
+        if val_error <= best_val_error or count == 10:    # reference :595-598
+            test_error = test(stores[2])
+            best_val_error, count = val_error, 0
+            log = ("Epoch: {:03d}, LR: {:7f}, Loss: {:.7f}, Validation MAE: {:.7f}, "
+                   "Test MAE: {:.7f}, Test MAE norm: {:.7f}").format(epoch, lr, loss, val_error, test_error,
+                                                                     test_error / float(std))
+            if rank == 0:
+                print("\n" + log + "\n")
+                with open(os.path.join(args.res_dir, "log.txt"), "a") as fh:
+                    fh.write(log + "\n")
+    if rank == 0:
+        torch.save(model.state_dict(), os.path.join(args.res_dir, "model_checkpoint{}.pth".format(args.epochs)))
+        print(cmd_input[:-1])
+        print(log)
+        with open(os.path.join(args.res_dir, "log.txt"), "a") as fh:
+            fh.write(log + "\n")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
