@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--lr", type=float, default=1e-2)
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no_breakdown", action="store_true")
+    ap.add_argument("--path", choices=("engine", "autograd"), default="engine",
+                    help="engine: one esc_engine_train_step call per step; autograd: per-op torch.autograd path")
     return ap.parse_args()
 
 
@@ -97,15 +99,19 @@ def main():
     E.parallel.broadcast_parameters(model, 0)               # identical replicas
     opt = E.optim.FlatAdam(model.parameters(), lr=args.lr)
     model.train()
+    engine = E.StepEngine(model) if args.path == "engine" else None
 
     stats = dict(graphs=0, nodes=0, edges=0, nnz=0)
 
     def step(i, count=False):
         b = store.collate(batch_ids[i % nb])
-        opt.zero_grad()
-        pred = model(b)
-        loss = E.ops.l1_loss(pred, b.y)
-        loss.backward()
+        if engine is not None:
+            loss = engine.train_step(b)                     # forward + L1 + backward, gradients overwritten
+        else:
+            opt.zero_grad()
+            pred = model(b)
+            loss = E.ops.l1_loss(pred, b.y)
+            loss.backward()
         if world > 1:                                       # ONE RCCL all-reduce: grad*n_local ++ [n_local]
             opt.all_reduce_weighted(b.x.size(0))
         opt.step()
@@ -196,7 +202,7 @@ def main():
         "config": {"workload": "count_cycle-shaped random regular graphs (n in 10/15/20/30), target=triangles, "
                                "NestedGIN_eff h=%d layers=%d hidden=%d, bs=%d per GPU (configs[1])"
                                % (args.h, args.layers, args.hidden, args.batch_size),
-                   "global_batch": args.batch_size * world, "parallelism": "dp%d graph-sharded" % world,
+                   "global_batch": args.batch_size * world, "parallelism": "dp%d graph-sharded" % world, "step_path": args.path,
                    "nodes_per_batch": round(N_avg, 1), "edges_per_batch": round(E_avg, 1),
                    "nnz_per_batch": round(stats["nnz"] / args.steps, 1)},
         "edges_aggregated_per_s": round(edges_agg_per_s, 1),

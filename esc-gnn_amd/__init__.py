@@ -11,6 +11,7 @@ from .plan import BatchPlan, plan_of  # noqa: F401
 from . import _native, ops, optim, parallel  # noqa: F401
 from .nn import GINEConv, Linear, global_add_pool, global_mean_pool  # noqa: F401
 from .run_graphcount import NestedGIN_eff  # noqa: F401
+from .engine import StepEngine  # noqa: F401
 from .store import DeviceGraphStore, DeviceLoader  # noqa: F401
 from .utils_edge_efficient import create_subgraphs, create_subgraphs_many  # noqa: F401
 

@@ -38,7 +38,7 @@ SIGNATURES = {
     "esc_bag_bwd_scratch": [I64, I64],
     "esc_bag_bwd_table": [P, I64, I64, P, P, P, P, I64, I64, P, P, P],
     "esc_gine_aggregate_fwd": [P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P],
-    "esc_gine_aggregate_bwd": [P, I64, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, P, P],
+    "esc_gine_aggregate_bwd": [P, I64, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P],
     "esc_reduce_sum": [P, I64, P, P],
     "esc_linear_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
     "esc_tune_set": [I32, I32],
@@ -46,9 +46,14 @@ SIGNATURES = {
     "esc_linear_bwd_weight_scratch": [I64, I64, I64],
     "esc_linear_bwd_weight": [P, I64, P, I64, P, P, I64, I64, I64, P, I64, P, P, P],
     "esc_bn_scratch": [I64],
-    "esc_bn_stats": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P],
+    "esc_bn_stats": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P, P],
     "esc_bn_apply": [P, I64, I64, I64, P, P, P, P, I32, P, I64, P],
-    "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, I32, P, I64, P, P, P, P],
+    "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, I64, P, P, P, P],
+    "esc_affine_act": [P, I64, I64, I64, P, P, I32, P, I64, P],
+    "esc_bn_eval_coef": [P, P, P, P, F32, I64, P, P, P],
+    "esc_engine_workspace_floats": [P, I64, I64, I64],
+    "esc_engine_train_step": [P, P, P, I64, P, P, P],
+    "esc_engine_predict": [P, P, P, P, P],
     "esc_l1_loss": [P, P, I64, I64, F32, P, P, P],
     "esc_adam_step": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P],
     "esc_collate_cols": [P, I64, P, I64, P, P, P, P],
@@ -59,7 +64,7 @@ SIGNATURES = {
 }
 _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
-        "esc_features_scratch_bytes": c_int64}
+        "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64}
 
 
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
                                                     const int* __restrict__ out_dst,
                                                     const float* __restrict__ eps_p, int N, int C,
                                                     float* __restrict__ d_e, int64_t ld_de,
-                                                    float* __restrict__ dx, int64_t ld_dx,
+                                                    float* __restrict__ dx, int64_t ld_dx, int accumulate_dx,
                                                     float* __restrict__ deps_part) {
   const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   if (node >= N) return;
@@ -179,10 +179,16 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
     if (dx != nullptr) {
       float* po = dx + (size_t)node * ld_dx + c;
       if constexpr (VEC == 4) {
-        *reinterpret_cast<float4*>(po) = make_float4(fmaf(one_eps, gi[0], acc[0]), fmaf(one_eps, gi[1], acc[1]),
-                                                     fmaf(one_eps, gi[2], acc[2]), fmaf(one_eps, gi[3], acc[3]));
+        float4 o = make_float4(fmaf(one_eps, gi[0], acc[0]), fmaf(one_eps, gi[1], acc[1]),
+                               fmaf(one_eps, gi[2], acc[2]), fmaf(one_eps, gi[3], acc[3]));
+        if (accumulate_dx) {
+          const float4 prev = *reinterpret_cast<const float4*>(po);
+          o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+        }
+        *reinterpret_cast<float4*>(po) = o;
       } else {
-        *po = fmaf(one_eps, gi[0], acc[0]);
+        const float o = fmaf(one_eps, gi[0], acc[0]);
+        *po = accumulate_dx ? *po + o : o;
       }
     }
   }
@@ -242,7 +248,7 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                            const float* g, int64_t ld_g, const int32_t* out_ptr,
                            const int32_t* out_edge, const int32_t* out_dst, const float* eps,
                            int64_t N, int64_t C, float* d_e, int64_t ld_de, float* dx,
-                           int64_t ld_dx, float* deps_part, void* stream) {
+                           int64_t ld_dx, int accumulate_dx, float* deps_part, void* stream) {
   ESC_REQUIRE(x && g && out_ptr && eps, "esc_gine_aggregate_bwd: null pointer");
   ESC_REQUIRE(N >= 0 && C > 0 && ld_x >= C && ld_e >= C && ld_g >= C && ld_de >= C && (!dx || ld_dx >= C),
               "esc_gine_aggregate_bwd: bad sizes");
@@ -255,9 +261,9 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                    esc::aligned16(d_e) && (!dx || esc::aligned16(dx));
   const int64_t blocks = esc::cdiv(N, 4);
   if (vec)
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part);
   else
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, deps_part);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd");
   return ESC_OK;
 }

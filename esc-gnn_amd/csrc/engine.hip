@@ -1,0 +1,248 @@
+// engine.hip — one host call = one NestedGIN_eff training step (forward + L1 + backward) or one
+// eval-mode forward.  Orchestrates the kernels of this library from C++ so that the per-op host
+// overhead of the Python/autograd path disappears, and applies the cross-op fusions a per-op
+// interface cannot express:
+//   * BatchNorm(+ReLU) is applied by the CONSUMER: esc_bn_stats emits (scale, shift) and the next
+//     GEMM applies relu(x*scale+shift) while staging its A (or, for weight gradients, B) operand.
+//     z_emb (E x H) and the hidden activation of every MLP are never written to memory; the backward
+//     recomputes the ReLU mask from the pre-BN value.
+//   * layer outputs are materialised directly into their slice of the [N,(L+1)H] concatenation buffer
+//     (reference: torch.cat(xs, dim=1), run_graphcount.py:181), and d(cat) slices are consumed in place;
+//     the aggregate backward accumulates dx into the previous layer's slice.
+//   * d(z_emb) = sum_l d_e_l * W_lin_l accumulates inside the dX GEMM epilogue.
+// Model composition followed: /root/reference/run_graphcount.py:134-194 (graph_pred=False, dropout=0,
+// use_cycle=True — the configuration run_graphcount.py:465 instantiates).
+#include "common.h"
+
+namespace esc {
+
+struct Arena {
+  float* base;
+  int64_t off;
+  float* take(int64_t n) {
+    float* p = base ? base + off : nullptr;
+    off += (n + 63) & ~63LL;          // 256-byte granules keep every buffer float4-aligned
+    return p;
+  }
+};
+
+struct BnWs { float *mean, *invstd, *scale, *shift; };
+struct MlpWs { float *Y0, *Y1; BnWs b0, b1; };
+
+struct Layout {
+  int64_t N, E, Z, H, L, C0, W;   // W = (L+1)*H
+  // forward state
+  float *Zb, *Yz; BnWs zb0, zb1;
+  float* e[ESC_MAX_LAYERS]; float* agg[ESC_MAX_LAYERS]; MlpWs conv[ESC_MAX_LAYERS];
+  MlpWs xemb; float *cat, *Yl; BnWs bl; float *pred, *dpred;
+  // backward scratch
+  float *dcat, *dAl, *dT1, *dT2, *dagg, *d_e, *dZemb, *dAz, *deps_part;
+  float *bn_scratch, *bag_scratch, *slabs;
+  int64_t total;
+};
+
+static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); return w; }
+
+static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z, float* base, bool train) {
+  Layout y{};
+  Arena a{base, 0};
+  const int64_t H = m->hidden, L = m->num_layers, C0 = m->in_dim;
+  y.N = N; y.E = E; y.Z = Z; y.H = H; y.L = L; y.C0 = C0; y.W = (L + 1) * H;
+  y.Zb = a.take(E * H); y.Yz = a.take(E * H); y.zb0 = take_bn(a, H); y.zb1 = take_bn(a, H);
+  for (int l = 0; l < L; ++l) {
+    const int64_t C = l == 0 ? C0 : H;
+    y.e[l] = a.take(E * C);
+    y.agg[l] = a.take(N * C);
+    y.conv[l].Y0 = a.take(N * H); y.conv[l].Y1 = a.take(N * H);
+    y.conv[l].b0 = take_bn(a, H); y.conv[l].b1 = take_bn(a, H);
+  }
+  y.xemb.Y0 = a.take(N * H); y.xemb.Y1 = a.take(N * H); y.xemb.b0 = take_bn(a, H); y.xemb.b1 = take_bn(a, H);
+  y.cat = a.take(N * y.W); y.Yl = a.take(N * H); y.bl = take_bn(a, H);
+  y.pred = a.take(N); y.dpred = a.take(N);
+  y.bn_scratch = a.take(esc_bn_scratch(H));
+  if (train) {
+    y.dcat = a.take(N * y.W); y.dAl = a.take(N * H); y.dT1 = a.take(N * H); y.dT2 = a.take(N * H);
+    y.dagg = a.take(N * H); y.d_e = a.take(E * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
+    y.deps_part = a.take(N);
+    y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
+    int64_t sl = esc_linear_bwd_weight_scratch(E, H, H);
+    const int64_t s2 = esc_linear_bwd_weight_scratch(N, H, y.W);
+    if (s2 > sl) sl = s2;
+    y.slabs = a.take(sl);
+  }
+  y.total = a.off;
+  return y;
+}
+
+#define ESC_TRY(call)            \
+  do {                           \
+    int rc__ = (call);           \
+    if (rc__ != ESC_OK) return rc__; \
+  } while (0)
+
+struct Ctx {
+  const esc_nested_gin_t* m;
+  const esc_batch_t* b;
+  Layout y;
+  void* s;
+  bool train;
+};
+
+static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const esc_bn_t& bn, const BnWs& w) {
+  const int64_t C = c.y.H;
+  if (c.train)
+    return esc_bn_stats(X, ld, M, C, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var,
+                        bn.gamma, bn.beta, w.scale, w.shift, c.y.bn_scratch, c.s);
+  return esc_bn_eval_coef(bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, C, w.scale, w.shift, c.s);
+}
+
+// Linear, BN, ReLU, Linear, BN, ReLU  (reference :65-73, :78-87) -> out (materialised, ld_out)
+static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
+                       float* out, int64_t ld_out) {
+  const int64_t H = c.y.H;
+  ESC_TRY(esc_linear_fwd(A, ld_a, p.lin0.w, p.lin0.in_dim, p.lin0.b, nullptr, nullptr, M, H, p.lin0.in_dim, w.Y0, H, nullptr, c.s));
+  ESC_TRY(bn_coeffs(c, w.Y0, H, M, p.bn0, w.b0));
+  ESC_TRY(esc_linear_fwd(w.Y0, H, p.lin1.w, H, p.lin1.b, w.b0.scale, w.b0.shift, M, H, H, w.Y1, H, nullptr, c.s));
+  ESC_TRY(bn_coeffs(c, w.Y1, H, M, p.bn1, w.b1));
+  return esc_affine_act(w.Y1, H, M, H, w.b1.scale, w.b1.shift, 1, out, ld_out, c.s);
+}
+
+// given dOut (grad of the materialised output `out`), produce parameter grads and, if dA != NULL, dA
+static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
+                        const float* out, int64_t ld_out, const float* dOut, int64_t ld_dout, float* dA,
+                        int64_t ld_da) {
+  const Layout& y = c.y;
+  const int64_t H = y.H;
+  ESC_TRY(esc_bn_bwd(w.Y1, H, out, ld_out, dOut, ld_dout, M, H, w.b1.mean, w.b1.invstd, p.bn1.gamma, p.bn1.beta, 1,
+                     y.dT1, H, p.bn1.dgamma, p.bn1.dbeta, y.bn_scratch, c.s));
+  ESC_TRY(esc_linear_bwd_weight(y.dT1, H, w.Y0, H, w.b0.scale, w.b0.shift, M, H, H, p.lin1.dw, H, p.lin1.db, y.slabs, c.s));
+  ESC_TRY(esc_linear_bwd_input(y.dT1, H, p.lin1.w, H, M, H, H, y.dT2, H, 0, c.s));
+  ESC_TRY(esc_bn_bwd(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, 1,
+                     y.dT2, H, p.bn0.dgamma, p.bn0.dbeta, y.bn_scratch, c.s));
+  const int64_t K = p.lin0.in_dim;
+  ESC_TRY(esc_linear_bwd_weight(y.dT2, H, A, ld_a, nullptr, nullptr, M, H, K, p.lin0.dw, K, p.lin0.db, y.slabs, c.s));
+  if (dA) ESC_TRY(esc_linear_bwd_input(y.dT2, H, p.lin0.w, K, M, H, K, dA, ld_da, 0, c.s));
+  return ESC_OK;
+}
+
+static int forward(const Ctx& c) {
+  const esc_nested_gin_t* m = c.m;
+  const esc_batch_t* b = c.b;
+  const Layout& y = c.y;
+  const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W;
+  // ESC bag + z_embedding (reference :155-156)
+  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, c.s));
+  ESC_TRY(bn_coeffs(c, y.Zb, H, E, m->zbn0, y.zb0));
+  ESC_TRY(esc_linear_fwd(y.Zb, H, m->zlin.w, H, m->zlin.b, y.zb0.scale, y.zb0.shift, E, H, H, y.Yz, H, nullptr, c.s));
+  ESC_TRY(bn_coeffs(c, y.Yz, H, E, m->zbn1, y.zb1));                      // z_emb = relu(Yz*scale+shift), virtual
+  // xs[0] = x_embedding(x) (reference :166)
+  ESC_TRY(mlp_forward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W));
+  // GINE layers (reference :161, :167-175): xs[l+1] -> cat[:, (l+1)H : (l+2)H]
+  for (int l = 0; l < L; ++l) {
+    const esc_conv_t& cv = m->conv[l];
+    const int64_t C = l == 0 ? y.C0 : H;
+    const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
+    const int64_t ld_h = l == 0 ? y.C0 : W;
+    ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], C, nullptr, c.s));
+    ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W));
+  }
+  // readout (reference :183-189)
+  ESC_TRY(esc_linear_fwd(y.cat, W, m->lin1.w, W, m->lin1.b, nullptr, nullptr, N, H, W, y.Yl, H, nullptr, c.s));
+  ESC_TRY(bn_coeffs(c, y.Yl, H, N, m->bn_lin1, y.bl));
+  return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
+}
+
+static int backward(const Ctx& c) {
+  const esc_nested_gin_t* m = c.m;
+  const esc_batch_t* b = c.b;
+  const Layout& y = c.y;
+  const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W;
+  // lin2 <- dpred
+  ESC_TRY(esc_linear_bwd_weight(y.dpred, 1, y.Yl, H, y.bl.scale, y.bl.shift, N, 1, H, m->lin2.dw, H, m->lin2.db, y.slabs, c.s));
+  ESC_TRY(esc_linear_bwd_input(y.dpred, 1, m->lin2.w, H, N, 1, H, y.dAl, H, 0, c.s));
+  ESC_TRY(esc_bn_bwd(y.Yl, H, nullptr, 0, y.dAl, H, N, H, y.bl.mean, y.bl.invstd, m->bn_lin1.gamma, m->bn_lin1.beta, 1,
+                     y.dAl, H, m->bn_lin1.dgamma, m->bn_lin1.dbeta, y.bn_scratch, c.s));
+  ESC_TRY(esc_linear_bwd_weight(y.dAl, H, y.cat, W, nullptr, nullptr, N, H, W, m->lin1.dw, W, m->lin1.db, y.slabs, c.s));
+  ESC_TRY(esc_linear_bwd_input(y.dAl, H, m->lin1.w, W, N, H, W, y.dcat, W, 0, c.s));
+  // GINE layers, last to first
+  for (int l = (int)L - 1; l >= 0; --l) {
+    const esc_conv_t& cv = m->conv[l];
+    const int64_t C = l == 0 ? y.C0 : H;
+    const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
+    const int64_t ld_h = l == 0 ? y.C0 : W;
+    ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W,
+                         y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C));
+    float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
+    ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
+                                   y.d_e, C, dx, W, 1, y.deps_part, c.s));
+    ESC_TRY(esc_reduce_sum(y.deps_part, N, cv.deps, c.s));
+    ESC_TRY(esc_linear_bwd_weight(y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, E, C, H, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
+    ESC_TRY(esc_linear_bwd_input(y.d_e, C, cv.lin.w, H, E, C, H, y.dZemb, H, l == (int)L - 1 ? 0 : 1, c.s));
+  }
+  // x_embedding (input x needs no gradient)
+  ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
+  // z_embedding + bag
+  ESC_TRY(esc_bn_bwd(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma, m->zbn1.beta, 1,
+                     y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, y.bn_scratch, c.s));
+  ESC_TRY(esc_linear_bwd_weight(y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, E, H, H, m->zlin.dw, H, m->zlin.db, y.slabs, c.s));
+  ESC_TRY(esc_linear_bwd_input(y.dZemb, H, m->zlin.w, H, E, H, H, y.dAz, H, 0, c.s));
+  ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
+                     y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, y.bn_scratch, c.s));
+  return esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
+                           y.bag_scratch, c.s);
+}
+
+static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* ws, bool train) {
+  ESC_REQUIRE(m && b && ws, "esc_engine: null pointer");
+  ESC_REQUIRE(m->num_layers >= 1 && m->num_layers <= ESC_MAX_LAYERS, "esc_engine: %ld layers unsupported", (long)m->num_layers);
+  ESC_REQUIRE(m->hidden > 0 && m->hidden % 4 == 0 && m->in_dim > 0, "esc_engine: hidden must be a multiple of 4");
+  ESC_REQUIRE(b->N >= 2 && b->E >= 2 && b->Z >= 0, "esc_engine: batch needs >= 2 nodes and edges (BatchNorm statistics)");
+  ESC_REQUIRE(b->x && b->in_ptr && b->row_ptr && (!train || (b->y && b->out_ptr && b->col_ptr)), "esc_engine: null batch arrays");
+  ESC_REQUIRE(aligned16(ws), "esc_engine: workspace must be 16-byte aligned");
+  return ESC_OK;
+}
+
+}  // namespace esc
+
+using namespace esc;
+
+extern "C" {
+
+int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z) {
+  if (!m || N < 0 || E < 0 || Z < 0) return -1;
+  return plan_layout(m, N, E, Z, nullptr, true).total;
+}
+
+int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
+                          int64_t loss_denom, float* loss, float* pred, void* stream) {
+  int rc = check(m, b, workspace, true);
+  if (rc) return rc;
+  ESC_REQUIRE(loss, "esc_engine_train_step: null loss pointer");
+  Ctx c{m, b, plan_layout(m, b->N, b->E, b->Z, workspace, true), stream, true};
+  ESC_TRY(forward(c));
+  ESC_TRY(esc_l1_loss(c.y.pred, b->y, b->N, loss_denom > 0 ? loss_denom : b->N, 1.0f, loss, c.y.dpred, stream));
+  if (pred) {
+    if (hipMemcpyAsync(pred, c.y.pred, sizeof(float) * (size_t)b->N, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+      set_error("esc_engine_train_step: prediction copy failed");
+      return ESC_ELAUNCH;
+    }
+  }
+  return backward(c);
+}
+
+int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
+                       void* stream) {
+  int rc = check(m, b, workspace, false);
+  if (rc) return rc;
+  ESC_REQUIRE(pred, "esc_engine_predict: null output");
+  Ctx c{m, b, plan_layout(m, b->N, b->E, b->Z, workspace, false), stream, false};
+  ESC_TRY(forward(c));
+  if (hipMemcpyAsync(pred, c.y.pred, sizeof(float) * (size_t)b->N, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    set_error("esc_engine_predict: prediction copy failed");
+    return ESC_ELAUNCH;
+  }
+  return ESC_OK;
+}
+
+}  // extern "C"

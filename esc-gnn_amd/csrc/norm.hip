@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restri
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ invstd,
                                                           float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var) {
+                                                          float* __restrict__ running_var,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (c >= C) return;
   const int lane = lane_id();
@@ -73,7 +76,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restri
   if (lane == 0) {
     const double var = m2 / (double)M;
     mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    invstd[c] = is;
+    if (scale) {      // consumer-side fused form: act(x) = relu(x*scale + shift)
+      const float sc = (gamma ? gamma[c] : 1.f) * is;
+      scale[c] = sc;
+      shift[c] = (beta ? beta[c] : 0.f) - (float)mu * sc;
+    }
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (double)(M - 1));
   }
@@ -118,18 +127,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ dY, int64_t ldg, int M,
                                                              int C, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int relu,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
                                                              float2* __restrict__ partial) {
   const int c = blockIdx.x * 64 + lane_id();
   const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int P = gridDim.y * 4;
   if (c >= C) return;
   const float mu = mean[c], is = invstd[c];
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
   for (int r = slot; r < M; r += P) {
     float g = dY[(size_t)r * ldg + c];
-    if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
     const float xh = (X[(size_t)r * ldx + c] - mu) * is;
+    if (relu) {   // forward output (if kept) or its recomputation decides the ReLU mask
+      const float yv = Y ? Y[(size_t)r * ldy + c] : fmaf(xh, ga, be);
+      if (!(yv > 0.f)) g = 0.f;
+    }
     s1 += g;
     s2 = fmaf(g, xh, s2);
   }
@@ -164,7 +179,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dY, int64_t ldg, int64_t M,
                                                            int C, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma, int relu,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int relu,
                                                            const float2* __restrict__ coef,
                                                            float* __restrict__ dX, int64_t ldd) {
   const int cv = C / VEC;
@@ -178,20 +194,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float4 g = *reinterpret_cast<const float4*>(dY + r * ldg + c);
       xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
       gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
-      if (relu) {
+      if (relu && Y) {
         const float4 y = *reinterpret_cast<const float4*>(Y + r * ldy + c);
         yv[0] = y.x; yv[1] = y.y; yv[2] = y.z; yv[3] = y.w;
       }
     } else {
       xv[0] = X[r * ldx + c];
       gv[0] = dY[r * ldg + c];
-      if (relu) yv[0] = Y[r * ldy + c];
+      if (relu && Y) yv[0] = Y[r * ldy + c];
     }
 #pragma unroll
     for (int t = 0; t < VEC; ++t) {
-      const float g = (relu && !(yv[t] > 0.f)) ? 0.f : gv[t];
       const float is = invstd[c + t];
       const float xh = (xv[t] - mean[c + t]) * is;
+      if (relu && !Y) yv[t] = fmaf(xh, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f);
+      const float g = (relu && !(yv[t] > 0.f)) ? 0.f : gv[t];
       const float2 k = coef[c + t];
       ov[t] = (gamma ? gamma[c + t] : 1.f) * is * (g - k.x - xh * k.y);
     }
@@ -201,6 +218,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       dX[r * ldd + c] = ov[0];
     }
   }
+}
+
+// y = relu?(x*scale + shift): materialises a consumer-side-fused BatchNorm(+ReLU) output
+template <int VEC>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int C,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int relu,
+                                                         float* __restrict__ Y, int64_t ldy) {
+  const int cv = C / VEC;
+  const int64_t total = M * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    if constexpr (VEC == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(X + r * ldx + c);
+      const float4 s4 = *reinterpret_cast<const float4*>(scale + c);
+      const float4 h4 = *reinterpret_cast<const float4*>(shift + c);
+      float4 o = make_float4(fmaf(q.x, s4.x, h4.x), fmaf(q.y, s4.y, h4.y), fmaf(q.z, s4.z, h4.z), fmaf(q.w, s4.w, h4.w));
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *reinterpret_cast<float4*>(Y + r * ldy + c) = o;
+    } else {
+      const float o = fmaf(X[r * ldx + c], scale[c], shift[c]);
+      Y[r * ldy + c] = relu ? fmaxf(o, 0.f) : o;
+    }
+  }
+}
+
+// inference-mode coefficients from running statistics
+__global__ __launch_bounds__(256) void bn_eval_coef_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int C,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = (gamma ? gamma[c] : 1.f) * (1.0f / sqrtf(rv[c] + eps));
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
 }
 
 static inline int rowblocks(int64_t M) { return (int)(M < 4 * NORM_ROWBLOCKS ? cdiv(M, 4) : NORM_ROWBLOCKS); }
@@ -214,15 +268,17 @@ extern "C" {
 int64_t esc_bn_scratch(int64_t C) { return (int64_t)NORM_ROWBLOCKS * 4 * C * 2 + 2 * C; }
 
 int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, float momentum,
-                 float* mean, float* invstd, float* running_mean, float* running_var, float* scratch,
+                 float* mean, float* invstd, float* running_mean, float* running_var,
+                 const float* gamma, const float* beta, float* scale, float* shift, float* scratch,
                  void* stream) {
+  ESC_REQUIRE((scale == nullptr) == (shift == nullptr), "esc_bn_stats: scale/shift must come together");
   ESC_REQUIRE(X && mean && invstd && scratch, "esc_bn_stats: null pointer");
   ESC_REQUIRE(M > 1 && C > 0 && ld_x >= C && M < (1LL << 31), "esc_bn_stats: need more than 1 row per channel (M=%ld, C=%ld)", (long)M, (long)C);
   hipStream_t s = (hipStream_t)stream;
   const int rb = rowblocks(M);
   esc::launch(ESC_K_NORM, bn_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
   ESC_CHECK_LAUNCH("esc_bn_stats.partial");
-  esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, eps, momentum, mean, invstd, running_mean, running_var);
+  esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, eps, momentum, mean, invstd, running_mean, running_var, gamma, beta, scale, shift);
   ESC_CHECK_LAUNCH("esc_bn_stats.finalize");
   return ESC_OK;
 }
@@ -243,26 +299,52 @@ int esc_bn_apply(const float* X, int64_t ld_x, int64_t M, int64_t C, const float
   return ESC_OK;
 }
 
+int esc_affine_act(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* scale, const float* shift,
+                   int relu, float* Y, int64_t ld_y, void* stream) {
+  ESC_REQUIRE(X && Y && scale && shift, "esc_affine_act: null pointer");
+  ESC_REQUIRE(M >= 0 && C > 0 && ld_x >= C && ld_y >= C, "esc_affine_act: bad sizes");
+  if (M == 0) return ESC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && aligned16(X) && aligned16(Y) &&
+                   aligned16(scale) && aligned16(shift);
+  const int64_t work = M * (vec ? C / 4 : C);
+  const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
+  if (vec) esc::launch(ESC_K_NORM, affine_act_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
+  else     esc::launch(ESC_K_NORM, affine_act_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
+  ESC_CHECK_LAUNCH("esc_affine_act");
+  return ESC_OK;
+}
+
+int esc_bn_eval_coef(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                     float eps, int64_t C, float* scale, float* shift, void* stream) {
+  ESC_REQUIRE(running_mean && running_var && scale && shift && C > 0, "esc_bn_eval_coef: bad argument");
+  esc::launch(ESC_K_NORM, bn_eval_coef_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+              running_mean, running_var, gamma, beta, eps, (int)C, scale, shift);
+  ESC_CHECK_LAUNCH("esc_bn_eval_coef");
+  return ESC_OK;
+}
+
 int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
                int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
-               const float* gamma, int relu, float* dX, int64_t ld_dx, float* dgamma, float* dbeta,
-               float* scratch, void* stream) {
-  ESC_REQUIRE(X && dY && dX && mean && invstd && scratch && (!relu || Y), "esc_bn_bwd: null pointer");
-  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && (!relu || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd: bad sizes");
+               const float* gamma, const float* beta, int relu, float* dX, int64_t ld_dx, float* dgamma,
+               float* dbeta, float* scratch, void* stream) {
+  ESC_REQUIRE(X && dY && dX && mean && invstd && scratch, "esc_bn_bwd: null pointer");
+  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && (!Y || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const int rb = rowblocks(M);
   float2* partial = (float2*)scratch;
   float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
-  esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, partial);
+  esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, gamma, beta, partial);
   ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
   esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
   ESC_CHECK_LAUNCH("esc_bn_bwd.finalize");
-  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) && (!relu || ld_y % 4 == 0) &&
-                   aligned16(X) && aligned16(dY) && aligned16(dX) && (!relu || aligned16(Y));
+  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) && (!Y || ld_y % 4 == 0) &&
+                   aligned16(X) && aligned16(dY) && aligned16(dX) && (!Y || aligned16(Y)) &&
+                   (!gamma || aligned16(gamma));
   const int64_t work = M * (vec ? C / 4 : C);
   const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
-  if (vec) esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
-  else     esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, relu, coef, dX, ld_dx);
+  if (vec) esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, beta, relu, coef, dX, ld_dx);
+  else     esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, beta, relu, coef, dX, ld_dx);
   ESC_CHECK_LAUNCH("esc_bn_bwd.apply");
   return ESC_OK;
 }

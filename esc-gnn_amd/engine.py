@@ -1,0 +1,159 @@
+"""StepEngine — NestedGIN_eff training/eval step as ONE call into libescgnn_hip.so
+(esc_engine_train_step / esc_engine_predict, csrc/engine.hip).
+
+The autograd path (`model(batch)`; `loss.backward()`) stays the drop-in interface; this is the fast
+path for the same module: it reads the module's parameters, writes the same `.grad` slots
+(views of the optimiser's flat gradient bucket) and updates the same BatchNorm buffers, so
+checkpoints, `optimizer.step()` and the data-parallel all-reduce are unchanged.
+"""
+import ctypes
+from ctypes import c_float, c_int64, c_void_p
+
+import torch
+
+from . import _native as nv
+from .plan import plan_of
+
+MAX_LAYERS = 16
+
+
+class _Linear(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("dw", c_void_p), ("db", c_void_p),
+                ("in_dim", c_int64), ("out_dim", c_int64)]
+
+
+class _BN(ctypes.Structure):
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("eps", c_float), ("momentum", c_float)]
+
+
+class _MLP(ctypes.Structure):
+    _fields_ = [("lin0", _Linear), ("bn0", _BN), ("lin1", _Linear), ("bn1", _BN)]
+
+
+class _Conv(ctypes.Structure):
+    _fields_ = [("eps", c_void_p), ("deps", c_void_p), ("nn", _MLP), ("lin", _Linear)]
+
+
+class _Model(ctypes.Structure):
+    _fields_ = [("num_layers", c_int64), ("hidden", c_int64), ("in_dim", c_int64), ("z_rows", c_int64),
+                ("z_table", c_void_p), ("dz_table", c_void_p),
+                ("zbn0", _BN), ("zlin", _Linear), ("zbn1", _BN), ("xemb", _MLP),
+                ("conv", _Conv * MAX_LAYERS), ("lin1", _Linear), ("bn_lin1", _BN), ("lin2", _Linear)]
+
+
+class _Batch(ctypes.Structure):
+    _fields_ = ([("N", c_int64), ("E", c_int64), ("Z", c_int64), ("x", c_void_p), ("y", c_void_p)] +
+                [(n, c_void_p) for n in ("in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst",
+                                         "row_ptr", "bag_idx", "bag_val", "col_ptr", "col_row", "col_val", "col_col")])
+
+
+def _grad_ptr(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data)
+    return p.grad.data_ptr()
+
+
+def _lin(mod):
+    s = _Linear()
+    s.w, s.dw = mod.weight.data_ptr(), _grad_ptr(mod.weight)
+    s.b, s.db = (mod.bias.data_ptr(), _grad_ptr(mod.bias)) if mod.bias is not None else (None, None)
+    s.in_dim, s.out_dim = mod.in_features, mod.out_features
+    return s
+
+
+def _bn(mod):
+    s = _BN()
+    s.gamma, s.beta = mod.weight.data_ptr(), mod.bias.data_ptr()
+    s.dgamma, s.dbeta = _grad_ptr(mod.weight), _grad_ptr(mod.bias)
+    s.running_mean, s.running_var = mod.running_mean.data_ptr(), mod.running_var.data_ptr()
+    s.eps, s.momentum = mod.eps, mod.momentum
+    return s
+
+
+def _mlp(seq):            # Sequential(Linear, Dropout, BN, ReLU, Linear, Dropout, BN, ReLU)
+    s = _MLP()
+    s.lin0, s.bn0, s.lin1, s.bn1 = _lin(seq[0]), _bn(seq[2]), _lin(seq[4]), _bn(seq[6])
+    return s
+
+
+class StepEngine(object):
+    def __init__(self, model):
+        if model.graph_pred or model.dropout != 0 or not model.use_cycle:
+            raise NotImplementedError("StepEngine covers the run_graphcount configuration "
+                                      "(graph_pred=False, dropout=0, use_cycle=True); use model(batch) otherwise")
+        if model.lin1.weight.device.type != "cuda":
+            raise RuntimeError("StepEngine runs on the HIP device only; there is no CPU fallback")
+        self.model = model
+        self._ws = None
+        self._bn_counters = [m.num_batches_tracked for m in model.modules()
+                             if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
+        self.refresh()
+
+    def refresh(self):
+        """(Re)read parameter / gradient / buffer addresses — call after the optimiser re-homed them."""
+        m = self.model
+        d = _Model()
+        convs = [m.conv1] + list(m.convs)
+        if len(convs) > MAX_LAYERS:
+            raise ValueError("at most %d layers" % MAX_LAYERS)
+        d.num_layers, d.hidden = len(convs), m.lin2.in_features
+        d.in_dim, d.z_rows = m.x_embedding[0].in_features, m.z_initial.num_embeddings
+        d.z_table, d.dz_table = m.z_initial.weight.data_ptr(), _grad_ptr(m.z_initial.weight)
+        d.zbn0, d.zlin, d.zbn1 = _bn(m.z_embedding[1]), _lin(m.z_embedding[3]), _bn(m.z_embedding[5])
+        d.xemb = _mlp(m.x_embedding)
+        for i, cv in enumerate(convs):
+            c = _Conv()
+            c.eps, c.deps = cv.eps.data_ptr(), _grad_ptr(cv.eps)
+            c.nn, c.lin = _mlp(cv.nn), _lin(cv.lin)
+            d.conv[i] = c
+        d.lin1, d.bn_lin1, d.lin2 = _lin(m.lin1), _bn(m.bn_lin1), _lin(m.lin2)
+        self._desc = d
+        self._keep = [p for p in m.parameters()]
+
+    def _batch(self, data, need_y):
+        plan = plan_of(data)
+        b = _Batch()
+        b.N, b.E, b.Z = plan.num_nodes, plan.num_edges, plan.nnz
+        x = data.x if data.x.is_contiguous() else data.x.contiguous()
+        b.x = x.data_ptr()
+        y = None
+        if need_y:
+            y = data.y.reshape(-1)
+            y = y if (y.dtype == torch.float32 and y.is_contiguous()) else y.float().contiguous()
+            if y.numel() != plan.num_nodes:
+                raise ValueError("StepEngine: expected one target per node")
+            b.y = y.data_ptr()
+        for f in ("in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst", "row_ptr", "bag_idx", "bag_val",
+                  "col_ptr", "col_row", "col_val", "col_col"):
+            setattr(b, f, getattr(plan, f).data_ptr())
+        return b, (x, y, plan)
+
+    def _workspace(self, b):
+        need = nv.lib().esc_engine_workspace_floats(ctypes.byref(self._desc), b.N, b.E, b.Z)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25), dtype=torch.float32, device=self.model.lin1.weight.device)
+        return self._ws
+
+    def train_step(self, data, loss_denom=None, return_pred=False):
+        """forward + L1 + backward; gradients land in the parameters' .grad (overwritten). Returns loss (0-d)."""
+        dev = self.model.lin1.weight.device
+        b, keep = self._batch(data, True)
+        ws = self._workspace(b)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        pred = torch.empty(b.N, dtype=torch.float32, device=dev) if return_pred else None
+        nv.call("esc_engine_train_step", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(),
+                int(loss_denom or 0), loss.data_ptr(), nv.ptr(pred), nv.stream())
+        if self._bn_counters:
+            torch._foreach_add_(self._bn_counters, 1)
+        return (loss.view(()), pred.view(-1, 1)) if return_pred else loss.view(())
+
+    @torch.no_grad()
+    def predict(self, data):
+        dev = self.model.lin1.weight.device
+        b, keep = self._batch(data, False)
+        ws = self._workspace(b)
+        pred = torch.empty(b.N, dtype=torch.float32, device=dev)
+        nv.call("esc_engine_predict", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(),
+                nv.stream())
+        return pred.view(-1, 1)

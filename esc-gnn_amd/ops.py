@@ -94,7 +94,7 @@ class _GineAggregate(Function):
         part = torch.empty(N, dtype=torch.float32, device=x.device) if need_eps else None
         nv.call("esc_gine_aggregate_bwd", nv.ptr(x), x.stride(0), nv.ptr(e), e.stride(0), nv.ptr(g), ldg,
                 nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, C,
-                nv.ptr(d_e), d_e.stride(0), nv.ptr(dx), C, nv.ptr(part), nv.stream())
+                nv.ptr(d_e), d_e.stride(0), nv.ptr(dx), C, 0, nv.ptr(part), nv.stream())
         deps = None
         if need_eps:
             deps = torch.empty(1, dtype=torch.float32, device=x.device)
@@ -173,7 +173,7 @@ class _BatchNormAct(Function):
         y = torch.empty((M, C), dtype=torch.float32, device=dev)
         s = nv.stream()
         nv.call("esc_bn_stats", nv.ptr(x), ldx, M, C, float(eps), float(momentum), nv.ptr(mean), nv.ptr(invstd),
-                nv.ptr(running_mean), nv.ptr(running_var), nv.ptr(scratch), s)
+                nv.ptr(running_mean), nv.ptr(running_var), None, None, None, None, nv.ptr(scratch), s)
         nv.call("esc_bn_apply", nv.ptr(x), ldx, M, C, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
                 int(relu), nv.ptr(y), C, s)
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
@@ -189,7 +189,7 @@ class _BatchNormAct(Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         nv.call("esc_bn_bwd", nv.ptr(x), x.stride(0), nv.ptr(y), C, nv.ptr(dy), ldg, M, C, nv.ptr(mean),
-                nv.ptr(invstd), nv.ptr(gamma), int(ctx.relu), nv.ptr(dx), C, nv.ptr(dgamma), nv.ptr(dbeta),
+                nv.ptr(invstd), nv.ptr(gamma), None, int(ctx.relu), nv.ptr(dx), C, nv.ptr(dgamma), nv.ptr(dbeta),
                 nv.ptr(ctx.scratch), nv.stream())
         return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None, None, None, None
 

@@ -67,7 +67,8 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                            const float* g, int64_t ld_g, const int32_t* out_ptr,
                            const int32_t* out_edge, const int32_t* out_dst, const float* eps,
                            int64_t N, int64_t C, float* d_e, int64_t ld_de, float* dx,
-                           int64_t ld_dx, float* deps_part, void* stream);
+                           int64_t ld_dx, int accumulate_dx /* dx += instead of = */, float* deps_part,
+                           void* stream);
 
 /* deterministic sum of n floats (fp64 accumulation) -> out[0]; finishes deps from deps_part. */
 int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream);
@@ -103,18 +104,28 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
  * stats: mean[C], invstd[C] of X[M,C] (biased variance, eps), optional running-stat update
  * (momentum, unbiased variance) exactly as torch does; then Y = relu?(gamma*(X-mean)*invstd+beta). */
 int64_t esc_bn_scratch(int64_t C);      /* floats of scratch the three calls below need */
+/* scale/shift (may be NULL together): the consumer-side fused form act(x) = relu(x*scale + shift),
+ * scale = gamma*invstd, shift = beta - mean*scale — fed to esc_linear_* as in_scale/in_shift. */
 int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, float momentum,
                  float* mean, float* invstd, float* running_mean, float* running_var,
+                 const float* gamma, const float* beta, float* scale, float* shift,
                  float* scratch, void* stream);
 int esc_bn_apply(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* mean,
                  const float* invstd, const float* gamma, const float* beta, int relu, float* Y,
                  int64_t ld_y, void* stream);
-/* backward of Y = relu?(BN(X)): dX, dgamma[C], dbeta[C].  Y is the forward output (relu mask;
- * may be NULL when relu == 0). */
+/* backward of Y = relu?(BN(X)): dX (may alias dY), dgamma[C], dbeta[C].  Y is the forward output used
+ * for the relu mask; NULL => the mask is recomputed from X, gamma, beta (output never materialised). */
 int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
                int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
-               const float* gamma, int relu, float* dX, int64_t ld_dx, float* dgamma, float* dbeta,
-               float* scratch, void* stream);
+               const float* gamma, const float* beta, int relu, float* dX, int64_t ld_dx,
+               float* dgamma, float* dbeta, float* scratch, void* stream);
+
+/* Y = relu?(X*scale + shift) — materialises a BatchNorm(+ReLU) output from its fused coefficients */
+int esc_affine_act(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* scale,
+                   const float* shift, int relu, float* Y, int64_t ld_y, void* stream);
+/* inference-mode coefficients from running statistics: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale */
+int esc_bn_eval_coef(const float* running_mean, const float* running_var, const float* gamma,
+                     const float* beta, float eps, int64_t C, float* scale, float* shift, void* stream);
 
 /* ---- a-11 loss + optimiser (run_graphcount.py:478,500-505) -------------------------------- */
 /* loss[0] = sum_i |pred_i - y_i| / denom ; dpred_i = sign(pred_i - y_i) * grad_scale / denom
@@ -126,6 +137,40 @@ int esc_l1_loss(const float* pred, const float* y, int64_t M, int64_t denom, flo
  * `step` is the 1-based step number. */
 int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+
+/* ---- whole-step engine: NestedGIN_eff forward + L1 + backward in ONE host call ---------------------
+ * (run_graphcount.py:134-194 forward, :500-503 loss/backward).  The host passes pointer tables of the
+ * model's parameters / gradient slots / BatchNorm buffers and of the batch + plan; every kernel above
+ * is enqueued from C++ (no per-op host round trip) with BatchNorm+ReLU fused into the consumer GEMMs
+ * (z_emb and the hidden MLP activations are never materialised) and layer outputs written straight
+ * into the [N,(L+1)H] concatenation buffer.  Gradients are WRITTEN (not accumulated) into the d* slots. */
+#define ESC_MAX_LAYERS 16
+typedef struct esc_linear_t { const float* w; const float* b; float* dw; float* db; int64_t in_dim, out_dim; } esc_linear_t;
+typedef struct esc_bn_t { const float* gamma; const float* beta; float* dgamma; float* dbeta;
+                          float* running_mean; float* running_var; float eps, momentum; } esc_bn_t;
+typedef struct esc_mlp_t { esc_linear_t lin0; esc_bn_t bn0; esc_linear_t lin1; esc_bn_t bn1; } esc_mlp_t;
+typedef struct esc_conv_t { const float* eps; float* deps; esc_mlp_t nn; esc_linear_t lin; } esc_conv_t;
+typedef struct esc_nested_gin_t {
+  int64_t num_layers, hidden, in_dim, z_rows;
+  const float* z_table; float* dz_table;                 /* z_initial.weight */
+  esc_bn_t zbn0; esc_linear_t zlin; esc_bn_t zbn1;       /* z_embedding.{1,3,5} */
+  esc_mlp_t xemb;                                        /* x_embedding */
+  esc_conv_t conv[ESC_MAX_LAYERS];                       /* conv1, convs.* */
+  esc_linear_t lin1; esc_bn_t bn_lin1; esc_linear_t lin2;
+} esc_nested_gin_t;
+typedef struct esc_batch_t {
+  int64_t N, E, Z;
+  const float* x; const float* y;                        /* x [N,in_dim]; y [N] (train only) */
+  const int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
+  const int32_t *row_ptr, *bag_idx, *bag_val, *col_ptr, *col_row, *col_val, *col_col;
+} esc_batch_t;
+int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z);
+/* loss[0] = sum|pred-y| / loss_denom (loss_denom <= 0: N).  pred (may be NULL): float[N]. */
+int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
+                          int64_t loss_denom, float* loss, float* pred, void* stream);
+/* eval-mode forward (running statistics, no gradient state kept): pred float[N] */
+int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
+                       void* stream);
 
 /* ---- a-5 collate (batch.py:25-149): gather B graphs out of the HBM-resident dataset store ------
  * The store keeps the reference's InMemoryDataset layout (per-key concatenation + slice pointers,
