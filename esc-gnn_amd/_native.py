@@ -42,6 +42,7 @@ SIGNATURES = {
     "esc_reduce_sum": [P, I64, P, P],
     "esc_linear_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
     "esc_tune_set": [I32, I32],
+    "esc_debug_gemm_occupancy": [I32],
     "esc_linear_bwd_input": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
     "esc_linear_bwd_weight_scratch": [I64, I64, I64],
     "esc_linear_bwd_weight": [P, I64, P, I64, P, P, I64, I64, I64, P, I64, P, P, P],

@@ -143,28 +143,31 @@ __global__ __launch_bounds__(256) void bag_bwd_pass1(const float* __restrict__ d
   }
 }
 
+// Pass 2: one WORKGROUP per column.  Its 4 waves take the column's chunk partials round-robin
+// (wave w sums chunks q0+w, q0+w+4, ...), then the 4 wave sums are added in wave order through LDS:
+// a fixed summation tree => bitwise reproducible, and a 15 000-entry column no longer serialises
+// 230 dependent row reads in one wave.
 template <int VEC>
 __global__ __launch_bounds__(256) void bag_bwd_pass2(int H, const int* __restrict__ col_ptr, int n_cols,
                                                      float* __restrict__ dtable,
                                                      const float* __restrict__ partials) {
-  const int col = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  extern __shared__ float sh[];                    // [3][H] : sums of waves 1..3
+  const int col = blockIdx.x;
   if (col >= n_cols) return;
-  const int cb = uniform(col_ptr[col]);
-  const int ce = uniform(col_ptr[col + 1]);
-  const int lane = lane_id();
+  const int cb = col_ptr[col];
+  const int ce = col_ptr[col + 1];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
   const bool empty = ce == cb;
   const int q0 = cb / BAG_CH;
   const int q1 = empty ? q0 : (ce - 1) / BAG_CH;
-  const bool interior = !empty && q0 == q1;
-  // a column confined to one chunk was fully handled by pass 1 (it is "interior" there iff
-  // cb >= chunk begin and ce <= chunk end, which q0 == q1 implies)
-  if (interior) return;
+  if (!empty && q0 == q1) return;                  // column confined to one chunk: pass 1 wrote it
   for (int c0 = lane * VEC; c0 < H; c0 += WAVE * VEC) {
     float acc[VEC];
 #pragma unroll
     for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
     if (!empty) {
-      for (int q = q0; q <= q1; ++q) {
+#pragma unroll 4
+      for (int q = q0 + wave; q <= q1; q += 4) {
         const int slot = (cb < q * BAG_CH) ? 0 : 1;
         const float* p = partials + ((size_t)q * 2 + slot) * H + c0;
         if constexpr (VEC == 4) {
@@ -175,12 +178,22 @@ __global__ __launch_bounds__(256) void bag_bwd_pass2(int H, const int* __restric
         }
       }
     }
-    float* o = dtable + (size_t)col * H + c0;
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    } else {
-      *o = acc[0];
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) sh[(wave - 1) * H + c0 + t] = acc[t];
     }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[t] = ((acc[t] + sh[c0 + t]) + sh[H + c0 + t]) + sh[2 * H + c0 + t];
+      float* o = dtable + (size_t)col * H + c0;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      } else {
+        *o = acc[0];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -225,11 +238,12 @@ int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* 
       esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass1<1>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
     ESC_CHECK_LAUNCH("esc_bag_bwd_table.pass1");
   }
-  const int64_t blocks2 = esc::cdiv(n_cols, 4);
+  const size_t lds2 = (size_t)3 * H * sizeof(float);
+  ESC_REQUIRE(lds2 <= 64 * 1024, "esc_bag_bwd_table: H too large");
   if (vec)
-    esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass2<4>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
+    esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass2<4>, dim3((unsigned)n_cols), dim3(256), lds2, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
   else
-    esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass2<1>, dim3(blocks2), dim3(256), 0, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
+    esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass2<1>, dim3((unsigned)n_cols), dim3(256), lds2, s, (int)H, col_ptr, (int)n_cols, dtable, partials);
   ESC_CHECK_LAUNCH("esc_bag_bwd_table.pass2");
   return ESC_OK;
 }

@@ -9,18 +9,28 @@
 namespace esc {
 
 // per-column running counts over the batch's graphs: prefix[b][c] = #entries of column c in graphs
-// 0..b-1 of the batch, total[c] = over all graphs.  One thread per column, coalesced across columns.
+// 0..b-1 of the batch, total[c] = over all graphs.  One wave per column: lanes take 64 graphs at a
+// time and a wave prefix scan replaces the serial dependent-load chain.
 __global__ __launch_bounds__(256) void collate_col_count_kernel(const int* __restrict__ col_cnt_all, int n_cols,
                                                                 const int64_t* __restrict__ graph_ids, int B,
                                                                 int* __restrict__ prefix, int* __restrict__ total) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (c >= n_cols) return;
+  const int lane = lane_id();
   int run = 0;
-  for (int b = 0; b < B; ++b) {
-    prefix[(size_t)b * n_cols + c] = run;
-    run += col_cnt_all[(size_t)graph_ids[b] * n_cols + c];
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + lane;
+    const int v = (b < B) ? col_cnt_all[(size_t)graph_ids[b] * n_cols + c] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (b < B) prefix[(size_t)b * n_cols + c] = run + incl - v;
+    run += __shfl(incl, 63, 64);
   }
-  total[c] = run;
+  if (lane == 0) total[c] = run;
 }
 
 // exclusive scan of n (<= a few thousand) ints by one workgroup -> out[n+1]
@@ -118,7 +128,7 @@ int esc_collate_cols(const int32_t* col_cnt_all, int64_t n_cols, const int64_t* 
   ESC_REQUIRE(col_cnt_all && graph_ids && col_prefix && col_total && col_ptr, "esc_collate_cols: null pointer");
   ESC_REQUIRE(n_cols > 0 && B > 0 && B < (1 << 24), "esc_collate_cols: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  esc::launch(ESC_K_COLLATE, collate_col_count_kernel, dim3((unsigned)cdiv(n_cols, 256)), dim3(256), 0, s, col_cnt_all, (int)n_cols, graph_ids, (int)B, col_prefix, col_total);
+  esc::launch(ESC_K_COLLATE, collate_col_count_kernel, dim3((unsigned)cdiv(n_cols, 4)), dim3(256), 0, s, col_cnt_all, (int)n_cols, graph_ids, (int)B, col_prefix, col_total);
   ESC_CHECK_LAUNCH("esc_collate_cols.count");
   esc::launch(ESC_K_COLLATE, small_scan_kernel, dim3(1), dim3(1024), 0, s, col_total, (int)n_cols, col_ptr);
   ESC_CHECK_LAUNCH("esc_collate_cols.scan");

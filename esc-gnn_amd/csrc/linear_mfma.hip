@@ -47,7 +47,7 @@ struct RedMajorTile {           // [BK][COLS+KPAD]
 // k-contiguous: rows r0.. of `src` (ld), reduction range [k0, k0+BK); element (r, k) valid iff
 // r < rows && k < kdim.  Optional per-k affine+relu (fused BatchNorm+ReLU of the producer).
 template <int ROWS, int BK, bool PRO>
-__device__ __forceinline__ void load_kcontig(const float* __restrict__ src, int64_t ld, int r0, int rows,
+__device__ __forceinline__ bool load_kcontig(const float* __restrict__ src, int64_t ld, int r0, int rows,
                                              int k0, int kdim, bool vec_ok,
                                              const float* __restrict__ sc, const float* __restrict__ sh,
                                              float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
@@ -59,24 +59,16 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ src, int6
   // out-of-range row is clamped to the last valid row and zeroed by a select — so hipcc emits straight
   // global_load_dwordx4 streams instead of a branch + vmcnt(0) per load.
   if (vec_ok && k0 + BK <= kdim) {
-    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (PRO) {
-      s4 = *reinterpret_cast<const float4*>(sc + k);
-      h4 = *reinterpret_cast<const float4*>(sh + k);
-    }
+    // RAW loads only: nothing here may depend on the loaded values, or hipcc waits for them on the spot
+    // and the prefetch collapses.  The affine+ReLU prologue and the row mask run in finish_kcontig(),
+    // right before the LDS store one K-step later.
 #pragma unroll
     for (int p = 0; p < T::PER_THREAD; ++p) {
       const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
       const int rc = min(r, rows - 1);
-      float4 v = *reinterpret_cast<const float4*>(src + (size_t)rc * ld + k);
-      if constexpr (PRO) {
-        v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
-      }
-      const bool ok = r < rows;
-      reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      reg[p] = *reinterpret_cast<const float4*>(src + (size_t)rc * ld + k);
     }
-    return;
+    return true;
   }
 #pragma unroll
   for (int p = 0; p < T::PER_THREAD; ++p) {
@@ -97,6 +89,32 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ src, int6
     }
     reg[p] = v;
   }
+  return false;
+}
+// prologue + row mask of a RAW k-contiguous tile (see load_kcontig)
+template <int ROWS, int BK, bool PRO>
+__device__ __forceinline__ void finish_kcontig(int r0, int rows, int k0, const float* __restrict__ sc,
+                                               const float* __restrict__ sh,
+                                               float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
+  using T = KContigTile<ROWS, BK>;
+  const int tid = threadIdx.x;
+  const int k = k0 + (tid % T::QPR) * 4;
+  float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRO) {
+    s4 = *reinterpret_cast<const float4*>(sc + k);
+    h4 = *reinterpret_cast<const float4*>(sh + k);
+  }
+#pragma unroll
+  for (int p = 0; p < T::PER_THREAD; ++p) {
+    const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
+    float4 v = reg[p];
+    if constexpr (PRO) {
+      v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+      v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+    }
+    const bool ok = r < rows;
+    reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  }
 }
 template <int ROWS, int BK>
 __device__ __forceinline__ void store_kcontig(float* __restrict__ lds, const float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
@@ -112,30 +130,21 @@ __device__ __forceinline__ void store_kcontig(float* __restrict__ lds, const flo
 // reduction-major: rows (reduction) [k0, k0+BK) of `src`, columns c0..c0+COLS; valid iff k < kdim && c < cols.
 // Optional per-COLUMN affine+relu (for act(X) in the weight gradient).
 template <int COLS, int BK, bool PRO>
-__device__ __forceinline__ void load_redmajor(const float* __restrict__ src, int64_t ld, int k0, int kdim,
+__device__ __forceinline__ bool load_redmajor(const float* __restrict__ src, int64_t ld, int k0, int kdim,
                                               int c0, int cols, bool vec_ok,
                                               const float* __restrict__ sc, const float* __restrict__ sh,
                                               float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;  // float4 per row
-  if (vec_ok && c0 + COLS <= cols) {   // block-uniform fast path: unconditional loads, clamped reduction row
+  if (vec_ok && c0 + COLS <= cols) {   // block-uniform fast path: RAW unconditional loads, clamped reduction row
 #pragma unroll
     for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
       const int f = tid + p * 256;
       const int kk = f / QPR, cq = f % QPR;
-      const int k = k0 + kk, c = c0 + cq * 4;
-      const int kc = min(k, kdim - 1);
-      float4 v = *reinterpret_cast<const float4*>(src + (size_t)kc * ld + c);
-      if constexpr (PRO) {
-        const float4 s4 = *reinterpret_cast<const float4*>(sc + c);
-        const float4 h4 = *reinterpret_cast<const float4*>(sh + c);
-        v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
-      }
-      const bool ok = k < kdim;
-      reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      const int kc = min(k0 + kk, kdim - 1);
+      reg[p] = *reinterpret_cast<const float4*>(src + (size_t)kc * ld + c0 + cq * 4);
     }
-    return;
+    return true;
   }
 #pragma unroll
   for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
@@ -157,6 +166,29 @@ __device__ __forceinline__ void load_redmajor(const float* __restrict__ src, int
       }
     }
     reg[p] = v;
+  }
+  return false;
+}
+template <int COLS, int BK, bool PRO>
+__device__ __forceinline__ void finish_redmajor(int k0, int kdim, int c0, const float* __restrict__ sc,
+                                                const float* __restrict__ sh,
+                                                float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
+  const int tid = threadIdx.x;
+  constexpr int QPR = COLS / 4;
+#pragma unroll
+  for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
+    const int f = tid + p * 256;
+    const int kk = f / QPR, cq = f % QPR;
+    float4 v = reg[p];
+    if constexpr (PRO) {
+      const int c = c0 + cq * 4;
+      const float4 s4 = *reinterpret_cast<const float4*>(sc + c);
+      const float4 h4 = *reinterpret_cast<const float4*>(sh + c);
+      v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+      v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+    }
+    const bool ok = k0 + kk < kdim;
+    reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   }
 }
 template <int COLS, int BK>
@@ -238,13 +270,24 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
   float4 ra1[ATile::PER_THREAD], rb1[BTile::PER_THREAD];
   float dbsum = 0.f;
 
-  auto gload = [&](int k0, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD]) {
-    if constexpr (A_KC) load_kcontig<BM, BK, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
-    else                load_redmajor<BM, BK, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
-    if constexpr (B_KC) load_kcontig<BN, BK, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
-    else                load_redmajor<BN, BK, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
+  // returns bit0: A tile is RAW (needs finish), bit1: B tile is RAW
+  auto gload = [&](int k0, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD]) -> int {
+    bool rawa, rawb;
+    if constexpr (A_KC) rawa = load_kcontig<BM, BK, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
+    else                rawa = load_redmajor<BM, BK, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
+    if constexpr (B_KC) rawb = load_kcontig<BN, BK, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
+    else                rawb = load_redmajor<BN, BK, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
+    return (rawa ? 1 : 0) | (rawb ? 2 : 0);
   };
-  auto lstore = [&](int buf, const float4 (&ra)[ATile::PER_THREAD], const float4 (&rb)[BTile::PER_THREAD]) {
+  auto lstore = [&](int buf, int k0, int raw, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD]) {
+    if (raw & 1) {
+      if constexpr (A_KC) finish_kcontig<BM, BK, PRO>(m0, g.rowsC, k0, g.pro_scale, g.pro_shift, ra);
+      else                finish_redmajor<BM, BK, false>(k0, red1, m0, nullptr, nullptr, ra);
+    }
+    if (raw & 2) {
+      if constexpr (B_KC) finish_kcontig<BN, BK, false>(n0, g.colsC, k0, nullptr, nullptr, rb);
+      else                finish_redmajor<BN, BK, PRO && !A_KC>(k0, red1, n0, g.pro_scale, g.pro_shift, rb);
+    }
     float* a_w = lds + buf * STAGE;
     float* b_w = a_w + ATile::FLOATS;
     if constexpr (A_KC) store_kcontig<BM, BK>(a_w, ra); else store_redmajor<BM, BK>(a_w, ra);
@@ -285,20 +328,21 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
   };
 
   const int nk = (red1 > red0) ? (red1 - red0 + BK - 1) / BK : 0;
-  if (nk > 0) gload(red0, ra0, rb0);
-  if (nk > 1) gload(red0 + BK, ra1, rb1);
-  if (nk > 0) lstore(0, ra0, rb0);
+  int raw0 = 0, raw1 = 0;
+  if (nk > 0) raw0 = gload(red0, ra0, rb0);
+  if (nk > 1) raw1 = gload(red0 + BK, ra1, rb1);
+  if (nk > 0) lstore(0, red0, raw0, ra0, rb0);
   __syncthreads();
   // invariant at the top of iteration kt: LDS[kt&1] = tile kt; register set (kt+1)&1 = tile kt+1 (in flight)
   for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) gload(red0 + (kt + 2) * BK, ra0, rb0);
+    if (kt + 2 < nk) raw0 = gload(red0 + (kt + 2) * BK, ra0, rb0);
     compute(0);
-    if (kt + 1 < nk) lstore(1, ra1, rb1);
+    if (kt + 1 < nk) lstore(1, red0 + (kt + 1) * BK, raw1, ra1, rb1);
     __syncthreads();
     if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) gload(red0 + (kt + 3) * BK, ra1, rb1);
+    if (kt + 3 < nk) raw1 = gload(red0 + (kt + 3) * BK, ra1, rb1);
     compute(1);
-    if (kt + 2 < nk) lstore(0, ra0, rb0);
+    if (kt + 2 < nk) lstore(0, red0 + (kt + 2) * BK, raw0, ra0, rb0);
     __syncthreads();
   }
 
@@ -328,14 +372,24 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
   }
 }
 
-// sum `splits` slabs of `n` floats in fixed order: out[i] = sum_s slab[s][i]
+// sum `splits` slabs in fixed order: out[i] = sum_s slab[s][i] for the N*K weight-gradient elements and,
+// in the same launch, the N bias-gradient partials that follow them in every slab group
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int splits,
-                                                          int cols, float* __restrict__ out, int64_t ld_out) {
+                                                          int cols, float* __restrict__ out, int64_t ld_out,
+                                                          const float* __restrict__ db_part, int rows,
+                                                          float* __restrict__ db) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int q = 0; q < splits; ++q) s += slabs[(size_t)q * n + i];
-  out[(i / cols) * ld_out + (i % cols)] = s;
+  if (i < n) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < splits; ++q) s += slabs[(size_t)q * n + i];
+    out[(i / cols) * ld_out + (i % cols)] = s;
+  } else if (db != nullptr && i - n < rows) {
+    const int64_t r = i - n;
+    float s = 0.f;
+    for (int q = 0; q < splits; ++q) s += db_part[(size_t)q * rows + r];
+    db[r] = s;
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
@@ -378,14 +432,35 @@ static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (l
 
 // tuning knobs (esc_tune_set): defaults chosen from scratch/gemm_bench.py sweeps on MI355X
 enum { KNOB_FWD_BIG = 0, KNOB_FWD_SMALL = 1, KNOB_DX_BIG = 2, KNOB_DX_SMALL = 3, KNOB_DW_TILE = 4,
-       KNOB_DW_BLOCKS = 5, KNOB_COUNT = 6 };
-static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512};
+       KNOB_DW_BLOCKS = 5, KNOB_DW_MIN_ROWS = 6, KNOB_COUNT = 7 };
+static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128};
 
 }  // namespace esc
 
 using namespace esc;
 
 extern "C" {
+
+// resident workgroups per CU the runtime predicts for the forward kernel of a tile id (diagnostics)
+int esc_debug_gemm_occupancy(int tile_id) {
+  int n = -1;
+#define ESC_OCC(BM_, BN_, WM_, WN_, BK_)                                                                  \
+  {                                                                                                       \
+    auto kern = gemm_tile_kernel<BM_, BN_, WM_, WN_, BK_, true, true, false, false>;                      \
+    const size_t lds = 2 * (KContigTile<BM_, BK_>::FLOATS + KContigTile<BN_, BK_>::FLOATS) * sizeof(float); \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, lds);                               \
+  }
+  switch (tile_id) {
+    case 0: ESC_OCC(128, 128, 2, 2, 32) break;
+    case 2: ESC_OCC(128, 32, 4, 1, 32) break;
+    case 3: ESC_OCC(128, 64, 2, 2, 32) break;
+    case 4: ESC_OCC(64, 64, 2, 2, 64) break;
+    default: ESC_OCC(64, 64, 2, 2, 32) break;
+  }
+#undef ESC_OCC
+  return n;
+}
 
 int esc_tune_set(int knob, int value) {
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
@@ -442,7 +517,7 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t K, int* splits, int* per_sp
   tile_dims(g_knob[KNOB_DW_TILE], &bm, &bn, &bk);
   const int64_t tiles = cdiv(N, bm) * cdiv(K, bn);
   int64_t want = cdiv(g_knob[KNOB_DW_BLOCKS], tiles);
-  int64_t max_splits = cdiv(M, 128);
+  int64_t max_splits = cdiv(M, g_knob[KNOB_DW_MIN_ROWS] < 128 ? 128 : g_knob[KNOB_DW_MIN_ROWS]);
   int64_t sp = want < 1 ? 1 : (want > max_splits ? max_splits : want);
   if (sp < 1) sp = 1;
   int64_t per = cdiv(cdiv(M, sp), bk) * bk;
@@ -479,12 +554,9 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
   else          { ESC_TILE_DISPATCH(id, false, false, false, true) }
   ESC_CHECK_LAUNCH("esc_linear_bwd_weight.tiles");
   const int64_t n = N * K;
-  esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, slabs, n, splits, (int)K, dW, ld_dw);
+  esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+              splits, (int)K, dW, ld_dw, g.db_part, (int)N, db);
   ESC_CHECK_LAUNCH("esc_linear_bwd_weight.reduce");
-  if (db) {
-    esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, g.db_part, N, splits, (int)N, db, N);
-    ESC_CHECK_LAUNCH("esc_linear_bwd_weight.bias");
-  }
   return ESC_OK;
 }
 

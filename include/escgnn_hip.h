@@ -83,9 +83,11 @@ int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, c
                    const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                    float* Y, int64_t ld_y, float* col_stats, void* stream);
 /* tile-shape / split knobs of the three GEMM forms (benchmark sweeps; defaults are the tuned ones):
- * 0 fwd tile for M>=8192, 1 fwd tile for small M, 2/3 same for dX, 4 dW tile, 5 dW target workgroups.
+ * 0 fwd tile for M>=8192, 1 fwd tile for small M, 2/3 same for dX, 4 dW tile, 5 dW target workgroups,
+ * 6 dW minimum reduction rows per split (>=128).
  * tile ids: 0 128x128xBK32, 1 64x64xBK32, 2 128x32xBK32, 3 128x64xBK32, 4 64x64xBK64. */
 int esc_tune_set(int knob, int value);
+int esc_debug_gemm_occupancy(int tile_id);   /* resident workgroups/CU the runtime predicts (diagnostics) */
 /* dX[M,K] = dY[M,N] * W[N,K]  (accumulate!=0: dX += ...) */
 int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
                          int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate,
