@@ -181,9 +181,14 @@ def main():
     alg_bytes = aggregate_bytes(N_avg, E_avg, args.hidden)
     avg_ms = ms_agg / max(n_agg, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if n_agg else 0.0
+    traffic = None                      # HBM bytes per launch from the PMC passes committed under profiles/
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic_agg_fwd.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
     roofline = dict(kernel="esc::agg_fwd_wave<4> (GINE aggregate forward = the scatter-add, C=%d)" % args.hidden,
                     bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None if traffic is None else int(traffic),
+                    traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 gfx950 correction; tools/parse_pmc.py",
                     launches=n_agg, avg_us=round(avg_ms * 1e3, 2), alg_bytes_per_launch=int(alg_bytes))
     extra = {}
     if "linear" in breakdown and breakdown["linear"]["ms_per_step"] > 0:
