@@ -26,6 +26,12 @@
 namespace esc {
 
 // ---- wide rows: one wave per node, VEC floats per lane per pass ---------------------------------
+// Edges are consumed in batches of AGG_BATCH with every row read of the batch issued before the first
+// use (2*AGG_BATCH loads in flight per wave); a short tail batch is padded by clamping the edge slot to
+// the node's last edge and masking its contribution, so the typical in-degree (6-7 for the counting
+// graphs) costs ONE round of memory latency instead of one per leftover edge.
+constexpr int AGG_BATCH = 8;
+
 template <int VEC>
 __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x, int64_t ld_x,
                                                     const float* __restrict__ e, int64_t ld_e,
@@ -41,16 +47,25 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
   const int end = uniform(in_ptr[node + 1]);
   const float one_eps = __fadd_rn(1.0f, *eps_p);
   for (int c = lane * VEC; c < C; c += WAVE * VEC) {
-    float acc[VEC];
+    float acc[VEC], self[VEC];
 #pragma unroll
     for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
-    int j = beg;
-    for (; j + 4 <= end; j += 4) {                 // 8 row reads in flight
-      float xv[4][VEC], ev[4][VEC];
+    {
+      const float* ps = x + (size_t)node * ld_x + c;
+      if constexpr (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(ps);
+        self[0] = a.x; self[1] = a.y; self[2] = a.z; self[3] = a.w;
+      } else {
+        self[0] = *ps;
+      }
+    }
+    for (int j = beg; j < end; j += AGG_BATCH) {
+      float xv[AGG_BATCH][VEC], ev[AGG_BATCH][VEC];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = uniform(in_edge[j + u]);
-        const int s = uniform(in_src[j + u]);
+      for (int u = 0; u < AGG_BATCH; ++u) {
+        const int jj = min(j + u, end - 1);                 // wave-uniform clamp (tail padding)
+        const int k = uniform(in_edge[jj]);
+        const int s = uniform(in_src[jj]);
         const float* px = x + (size_t)s * ld_x + c;
         const float* pe = e + (size_t)k * ld_e + c;
         if constexpr (VEC == 4) {
@@ -63,36 +78,21 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < AGG_BATCH; ++u) {
+        if (j + u < end) {                                  // wave-uniform: ascending-edge order is preserved
 #pragma unroll
-        for (int t = 0; t < VEC; ++t)
-          acc[t] = __fadd_rn(acc[t], fmaxf(__fadd_rn(xv[u][t], ev[u][t]), 0.f));
-    }
-    for (; j < end; ++j) {
-      const int k = uniform(in_edge[j]);
-      const int s = uniform(in_src[j]);
-      const float* px = x + (size_t)s * ld_x + c;
-      const float* pe = e + (size_t)k * ld_e + c;
-      if constexpr (VEC == 4) {
-        const float4 a = *reinterpret_cast<const float4*>(px);
-        const float4 b = *reinterpret_cast<const float4*>(pe);
-        acc[0] = __fadd_rn(acc[0], fmaxf(__fadd_rn(a.x, b.x), 0.f));
-        acc[1] = __fadd_rn(acc[1], fmaxf(__fadd_rn(a.y, b.y), 0.f));
-        acc[2] = __fadd_rn(acc[2], fmaxf(__fadd_rn(a.z, b.z), 0.f));
-        acc[3] = __fadd_rn(acc[3], fmaxf(__fadd_rn(a.w, b.w), 0.f));
-      } else {
-        acc[0] = __fadd_rn(acc[0], fmaxf(__fadd_rn(*px, *pe), 0.f));
+          for (int t = 0; t < VEC; ++t)
+            acc[t] = __fadd_rn(acc[t], fmaxf(__fadd_rn(xv[u][t], ev[u][t]), 0.f));
+        }
       }
     }
-    const float* ps = x + (size_t)node * ld_x + c;
     float* po = out + (size_t)node * ld_out + c;
     if constexpr (VEC == 4) {
-      const float4 a = *reinterpret_cast<const float4*>(ps);
       *reinterpret_cast<float4*>(po) =
-          make_float4(__fadd_rn(acc[0], __fmul_rn(one_eps, a.x)), __fadd_rn(acc[1], __fmul_rn(one_eps, a.y)),
-                      __fadd_rn(acc[2], __fmul_rn(one_eps, a.z)), __fadd_rn(acc[3], __fmul_rn(one_eps, a.w)));
+          make_float4(__fadd_rn(acc[0], __fmul_rn(one_eps, self[0])), __fadd_rn(acc[1], __fmul_rn(one_eps, self[1])),
+                      __fadd_rn(acc[2], __fmul_rn(one_eps, self[2])), __fadd_rn(acc[3], __fmul_rn(one_eps, self[3])));
     } else {
-      *po = __fadd_rn(acc[0], __fmul_rn(one_eps, *ps));
+      *po = __fadd_rn(acc[0], __fmul_rn(one_eps, self[0]));
     }
   }
 }
@@ -153,27 +153,38 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
     }
 #pragma unroll
     for (int t = 0; t < VEC; ++t) { acc[t] = 0.f; dot = fmaf(xi[t], gi[t], dot); }
-#pragma unroll 4
-    for (int j = beg; j < end; ++j) {
-      const int k = uniform(out_edge[j]);
-      const int d = uniform(out_dst[j]);
-      const float* pe = e + (size_t)k * ld_e + c;
-      const float* pg = g + (size_t)d * ld_g + c;
-      float* pd = d_e + (size_t)k * ld_de + c;
-      if constexpr (VEC == 4) {
-        const float4 ev = *reinterpret_cast<const float4*>(pe);
-        const float4 gv = *reinterpret_cast<const float4*>(pg);
-        float4 o;
-        o.x = (__fadd_rn(xi[0], ev.x) > 0.f) ? gv.x : 0.f;
-        o.y = (__fadd_rn(xi[1], ev.y) > 0.f) ? gv.y : 0.f;
-        o.z = (__fadd_rn(xi[2], ev.z) > 0.f) ? gv.z : 0.f;
-        o.w = (__fadd_rn(xi[3], ev.w) > 0.f) ? gv.w : 0.f;
-        *reinterpret_cast<float4*>(pd) = o;
-        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
-      } else {
-        const float o = (__fadd_rn(xi[0], *pe) > 0.f) ? *pg : 0.f;
-        *pd = o;
-        acc[0] += o;
+    for (int j = beg; j < end; j += AGG_BATCH) {          // all 2*AGG_BATCH row reads of a batch in flight
+      float ev[AGG_BATCH][VEC], gv[AGG_BATCH][VEC];
+      int kk[AGG_BATCH];
+#pragma unroll
+      for (int u = 0; u < AGG_BATCH; ++u) {
+        const int jj = min(j + u, end - 1);
+        kk[u] = uniform(out_edge[jj]);
+        const int d = uniform(out_dst[jj]);
+        const float* pe = e + (size_t)kk[u] * ld_e + c;
+        const float* pg = g + (size_t)d * ld_g + c;
+        if constexpr (VEC == 4) {
+          const float4 a = *reinterpret_cast<const float4*>(pe);
+          const float4 b = *reinterpret_cast<const float4*>(pg);
+          ev[u][0] = a.x; ev[u][1] = a.y; ev[u][2] = a.z; ev[u][3] = a.w;
+          gv[u][0] = b.x; gv[u][1] = b.y; gv[u][2] = b.z; gv[u][3] = b.w;
+        } else {
+          ev[u][0] = *pe; gv[u][0] = *pg;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < AGG_BATCH; ++u) {
+        if (j + u < end) {
+          float o[VEC];
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) {
+            o[t] = (__fadd_rn(xi[t], ev[u][t]) > 0.f) ? gv[u][t] : 0.f;
+            acc[t] += o[t];
+          }
+          float* pd = d_e + (size_t)kk[u] * ld_de + c;
+          if constexpr (VEC == 4) *reinterpret_cast<float4*>(pd) = make_float4(o[0], o[1], o[2], o[3]);
+          else *pd = o[0];
+        }
       }
     }
     if (dx != nullptr) {

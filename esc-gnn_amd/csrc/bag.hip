@@ -38,8 +38,28 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
     int j = beg;
-    // 4 table rows in flight per wave
-    for (; j + 4 <= end; j += 4) {
+    // 8 table rows in flight per wave
+    for (; j + 8 <= end; j += 8) {
+      float w[8][VEC];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = uniform(idx[j + u]);
+        v[u] = (float)uniform(val[j + u]);
+        const float* p = table + (size_t)r * H + c;
+        if constexpr (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(p);
+          w[u][0] = q.x; w[u][1] = q.y; w[u][2] = q.z; w[u][3] = q.w;
+        } else {
+          w[u][0] = *p;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) acc[t] = __fadd_rn(acc[t], __fmul_rn(w[u][t], v[u]));
+    }
+    if (j + 4 <= end) {
       float w[4][VEC];
       float v[4];
 #pragma unroll
@@ -58,6 +78,7 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < VEC; ++t) acc[t] = __fadd_rn(acc[t], __fmul_rn(w[u][t], v[u]));
+      j += 4;
     }
     for (; j < end; ++j) {
       const int r = uniform(idx[j]);

@@ -93,17 +93,10 @@ __device__ __forceinline__ bool load_kcontig(const float* __restrict__ src, int6
 }
 // prologue + row mask of a RAW k-contiguous tile (see load_kcontig)
 template <int ROWS, int BK, bool PRO>
-__device__ __forceinline__ void finish_kcontig(int r0, int rows, int k0, const float* __restrict__ sc,
-                                               const float* __restrict__ sh,
+__device__ __forceinline__ void finish_kcontig(int r0, int rows, float4 s4, float4 h4,
                                                float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
   using T = KContigTile<ROWS, BK>;
   const int tid = threadIdx.x;
-  const int k = k0 + (tid % T::QPR) * 4;
-  float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (PRO) {
-    s4 = *reinterpret_cast<const float4*>(sc + k);
-    h4 = *reinterpret_cast<const float4*>(sh + k);
-  }
 #pragma unroll
   for (int p = 0; p < T::PER_THREAD; ++p) {
     const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
@@ -170,20 +163,17 @@ __device__ __forceinline__ bool load_redmajor(const float* __restrict__ src, int
   return false;
 }
 template <int COLS, int BK, bool PRO>
-__device__ __forceinline__ void finish_redmajor(int k0, int kdim, int c0, const float* __restrict__ sc,
-                                                const float* __restrict__ sh,
+__device__ __forceinline__ void finish_redmajor(int k0, int kdim, float4 s4, float4 h4,
                                                 float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;
+  static_assert(256 % QPR == 0, "a thread keeps the same column quad for every pass");
 #pragma unroll
   for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
     const int f = tid + p * 256;
-    const int kk = f / QPR, cq = f % QPR;
+    const int kk = f / QPR;
     float4 v = reg[p];
     if constexpr (PRO) {
-      const int c = c0 + cq * 4;
-      const float4 s4 = *reinterpret_cast<const float4*>(sc + c);
-      const float4 h4 = *reinterpret_cast<const float4*>(sh + c);
       v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
       v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
     }
@@ -270,23 +260,47 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
   float4 ra1[ATile::PER_THREAD], rb1[BTile::PER_THREAD];
   float dbsum = 0.f;
 
+  // Prologue coefficients travel with the tile they belong to (loaded as RAW values next to it): fetching
+  // them at finish time would sit behind the NEXT tile's loads in the in-order vmcnt queue and drain the
+  // prefetch.  k-contiguous A: one (scale, shift) quad per K-step; reduction-major B: the thread's column
+  // quad never changes, so it is loaded once.
+  const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ps0 = one4, ph0 = zero4, ps1 = one4, ph1 = zero4, pcs = one4, pch = zero4;
+  bool pro_vec = false;
+  if constexpr (PRO) {
+    pro_vec = A_KC ? (g.a_vec != 0) : (g.b_vec != 0);   // host sets *_vec only if the coefficient vectors are 16-B aligned
+    if constexpr (!A_KC) {
+      const int c = n0 + (threadIdx.x % (BN / 4)) * 4;
+      if (pro_vec && c + 3 < g.colsC) {
+        pcs = *reinterpret_cast<const float4*>(g.pro_scale + c);
+        pch = *reinterpret_cast<const float4*>(g.pro_shift + c);
+      }
+    }
+  }
   // returns bit0: A tile is RAW (needs finish), bit1: B tile is RAW
-  auto gload = [&](int k0, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD]) -> int {
+  auto gload = [&](int k0, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD], float4& ps, float4& ph) -> int {
     bool rawa, rawb;
+    if constexpr (PRO && A_KC) {
+      const int k = k0 + (threadIdx.x % (BK / 4)) * 4;
+      if (pro_vec && k0 + BK <= red1) {
+        ps = *reinterpret_cast<const float4*>(g.pro_scale + k);
+        ph = *reinterpret_cast<const float4*>(g.pro_shift + k);
+      }
+    }
     if constexpr (A_KC) rawa = load_kcontig<BM, BK, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
     else                rawa = load_redmajor<BM, BK, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
     if constexpr (B_KC) rawb = load_kcontig<BN, BK, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
     else                rawb = load_redmajor<BN, BK, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
     return (rawa ? 1 : 0) | (rawb ? 2 : 0);
   };
-  auto lstore = [&](int buf, int k0, int raw, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD]) {
+  auto lstore = [&](int buf, int k0, int raw, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD], float4 ps, float4 ph) {
     if (raw & 1) {
-      if constexpr (A_KC) finish_kcontig<BM, BK, PRO>(m0, g.rowsC, k0, g.pro_scale, g.pro_shift, ra);
-      else                finish_redmajor<BM, BK, false>(k0, red1, m0, nullptr, nullptr, ra);
+      if constexpr (A_KC) finish_kcontig<BM, BK, PRO>(m0, g.rowsC, ps, ph, ra);
+      else                finish_redmajor<BM, BK, false>(k0, red1, zero4, zero4, ra);
     }
     if (raw & 2) {
-      if constexpr (B_KC) finish_kcontig<BN, BK, false>(n0, g.colsC, k0, nullptr, nullptr, rb);
-      else                finish_redmajor<BN, BK, PRO && !A_KC>(k0, red1, n0, g.pro_scale, g.pro_shift, rb);
+      if constexpr (B_KC) finish_kcontig<BN, BK, false>(n0, g.colsC, zero4, zero4, rb);
+      else                finish_redmajor<BN, BK, PRO && !A_KC>(k0, red1, pcs, pch, rb);
     }
     float* a_w = lds + buf * STAGE;
     float* b_w = a_w + ATile::FLOATS;
@@ -329,20 +343,20 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
 
   const int nk = (red1 > red0) ? (red1 - red0 + BK - 1) / BK : 0;
   int raw0 = 0, raw1 = 0;
-  if (nk > 0) raw0 = gload(red0, ra0, rb0);
-  if (nk > 1) raw1 = gload(red0 + BK, ra1, rb1);
-  if (nk > 0) lstore(0, red0, raw0, ra0, rb0);
+  if (nk > 0) raw0 = gload(red0, ra0, rb0, ps0, ph0);
+  if (nk > 1) raw1 = gload(red0 + BK, ra1, rb1, ps1, ph1);
+  if (nk > 0) lstore(0, red0, raw0, ra0, rb0, ps0, ph0);
   __syncthreads();
   // invariant at the top of iteration kt: LDS[kt&1] = tile kt; register set (kt+1)&1 = tile kt+1 (in flight)
   for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) raw0 = gload(red0 + (kt + 2) * BK, ra0, rb0);
+    if (kt + 2 < nk) raw0 = gload(red0 + (kt + 2) * BK, ra0, rb0, ps0, ph0);
     compute(0);
-    if (kt + 1 < nk) lstore(1, red0 + (kt + 1) * BK, raw1, ra1, rb1);
+    if (kt + 1 < nk) lstore(1, red0 + (kt + 1) * BK, raw1, ra1, rb1, ps1, ph1);
     __syncthreads();
     if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) raw1 = gload(red0 + (kt + 3) * BK, ra1, rb1);
+    if (kt + 3 < nk) raw1 = gload(red0 + (kt + 3) * BK, ra1, rb1, ps1, ph1);
     compute(1);
-    if (kt + 2 < nk) lstore(0, red0 + (kt + 2) * BK, raw0, ra0, rb0);
+    if (kt + 2 < nk) lstore(0, red0 + (kt + 2) * BK, raw0, ra0, rb0, ps0, ph0);
     __syncthreads();
   }
 
@@ -482,7 +496,8 @@ int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, c
   g.A = X; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.C = Y; g.ldc = ld_y; g.bias = bias;
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.db_part = nullptr;
   g.rowsC = (int)M; g.colsC = (int)N; g.red = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
-  g.a_vec = vec_ok(X, ld_x); g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
+  g.a_vec = vec_ok(X, ld_x) && (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
+  g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
   const int splits = 1;
   const int id = (N <= 32) ? 2 : (M >= 8192 ? g_knob[KNOB_FWD_BIG] : g_knob[KNOB_FWD_SMALL]);
   if (in_scale) { ESC_TILE_DISPATCH(id, true, true, true, false) }
@@ -548,7 +563,9 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
   g.pro_scale = in_scale; g.pro_shift = in_shift;
   g.db_part = slabs + (size_t)splits * N * K;
   g.rowsC = (int)N; g.colsC = (int)K; g.red = (int)M; g.red_per_split = per; g.accumulate = 0;
-  g.a_vec = vec_ok(dY, ld_dy); g.b_vec = vec_ok(X, ld_x); g.c_slab = 1;
+  g.a_vec = vec_ok(dY, ld_dy);
+  g.b_vec = vec_ok(X, ld_x) && (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
+  g.c_slab = 1;
   const int id = g_knob[KNOB_DW_TILE];
   if (in_scale) { ESC_TILE_DISPATCH(id, false, false, true, true) }
   else          { ESC_TILE_DISPATCH(id, false, false, false, true) }
