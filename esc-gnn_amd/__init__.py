@@ -17,3 +17,18 @@ from .utils_edge_efficient import create_subgraphs, create_subgraphs_many  # noq
 
 __all__ = ["create_subgraphs", "create_subgraphs_many", "Data", "Batch", "DataLoader", "BatchPlan", "plan_of", "GINEConv", "Linear",
            "NestedGIN_eff", "global_add_pool", "global_mean_pool", "ops"]
+
+
+def install_dropin():
+    """Register this package's modules under the reference's top-level module names, so that an unmodified
+    `from utils_edge_efficient import create_subgraphs`, `from batch import Batch`,
+    `from dataloader import DataLoader` or `from kernel.gin import NestedGIN_eff` resolves here."""
+    import sys
+    import types
+    from . import batch as _batch, dataloader as _dataloader, kernel_gin as _kernel_gin, utils_edge_efficient as _uee
+    sys.modules.setdefault("utils_edge_efficient", _uee)
+    sys.modules.setdefault("batch", _batch)
+    sys.modules.setdefault("dataloader", _dataloader)
+    pkg = sys.modules.setdefault("kernel", types.ModuleType("kernel"))
+    pkg.gin = _kernel_gin
+    sys.modules.setdefault("kernel.gin", _kernel_gin)

@@ -40,6 +40,8 @@ SIGNATURES = {
     "esc_gine_aggregate_fwd": [P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P],
     "esc_gine_aggregate_bwd": [P, I64, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P],
     "esc_reduce_sum": [P, I64, P, P],
+    "esc_segment_pool_fwd": [P, I64, P, I64, I64, I32, P, I64, P],
+    "esc_segment_pool_bwd": [P, I64, P, I64, I64, I32, P, I64, P],
     "esc_linear_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
     "esc_tune_set": [I32, I32],
     "esc_debug_gemm_occupancy": [I32],

@@ -209,6 +209,74 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
   }
 }
 
+// ---- graph readout: global_add_pool / global_mean_pool over the (sorted) node->graph vector -----------
+// (reference run_graphcount.py:179 graph_pred=True; zinc_models.py:602).  One wave per graph walks its
+// contiguous node range in order => bit-identical to a sequential index_add_.
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_pool_fwd(const float* __restrict__ x, int64_t ld_x,
+                                                        const int* __restrict__ seg_ptr, int G, int C, int mean,
+                                                        float* __restrict__ out, int64_t ld_out) {
+  const int gidx = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  if (gidx >= G) return;
+  const int lane = lane_id();
+  const int beg = uniform(seg_ptr[gidx]), end = uniform(seg_ptr[gidx + 1]);
+  const float cnt = (float)max(end - beg, 1);
+  for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+#pragma unroll 4
+    for (int r = beg; r < end; ++r) {
+      const float* p = x + (size_t)r * ld_x + c;
+      if constexpr (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        acc[0] = __fadd_rn(acc[0], q.x); acc[1] = __fadd_rn(acc[1], q.y);
+        acc[2] = __fadd_rn(acc[2], q.z); acc[3] = __fadd_rn(acc[3], q.w);
+      } else {
+        acc[0] = __fadd_rn(acc[0], *p);
+      }
+    }
+    if (mean) {
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[t] = acc[t] / cnt;
+    }
+    float* o = out + (size_t)gidx * ld_out + c;
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else *o = acc[0];
+  }
+}
+
+// dx[i,:] = g[graph(i),:] (/ count) — one wave per graph broadcasts its gradient row to its nodes
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_pool_bwd(const float* __restrict__ g, int64_t ld_g,
+                                                        const int* __restrict__ seg_ptr, int G, int C, int mean,
+                                                        float* __restrict__ dx, int64_t ld_dx) {
+  const int gidx = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  if (gidx >= G) return;
+  const int lane = lane_id();
+  const int beg = uniform(seg_ptr[gidx]), end = uniform(seg_ptr[gidx + 1]);
+  const float cnt = (float)max(end - beg, 1);
+  for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+    float v[VEC];
+    const float* p = g + (size_t)gidx * ld_g + c;
+    if constexpr (VEC == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(p);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      v[0] = *p;
+    }
+    if (mean) {
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) v[t] = v[t] / cnt;
+    }
+    for (int r = beg; r < end; ++r) {
+      float* o = dx + (size_t)r * ld_dx + c;
+      if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      else *o = v[0];
+    }
+  }
+}
+
 // deterministic single-block sum of n floats -> out[0] (fp64 accumulation)
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ v, int64_t n,
                                                           float* __restrict__ out) {
@@ -276,6 +344,28 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
   else
     esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd");
+  return ESC_OK;
+}
+
+int esc_segment_pool_fwd(const float* x, int64_t ld_x, const int32_t* seg_ptr, int64_t G, int64_t C, int mean,
+                         float* out, int64_t ld_out, void* stream) {
+  ESC_REQUIRE(x && seg_ptr && out, "esc_segment_pool_fwd: null pointer");
+  ESC_REQUIRE(G > 0 && C > 0 && ld_x >= C && ld_out >= C && G < (1LL << 31) / 64, "esc_segment_pool_fwd: bad sizes");
+  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_out % 4 == 0) && esc::aligned16(x) && esc::aligned16(out);
+  if (vec) esc::launch(-1, esc::segment_pool_fwd<4>, dim3((unsigned)esc::cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, seg_ptr, (int)G, (int)C, mean, out, ld_out);
+  else     esc::launch(-1, esc::segment_pool_fwd<1>, dim3((unsigned)esc::cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, seg_ptr, (int)G, (int)C, mean, out, ld_out);
+  ESC_CHECK_LAUNCH("esc_segment_pool_fwd");
+  return ESC_OK;
+}
+
+int esc_segment_pool_bwd(const float* g, int64_t ld_g, const int32_t* seg_ptr, int64_t G, int64_t C, int mean,
+                         float* dx, int64_t ld_dx, void* stream) {
+  ESC_REQUIRE(g && seg_ptr && dx, "esc_segment_pool_bwd: null pointer");
+  ESC_REQUIRE(G > 0 && C > 0 && ld_g >= C && ld_dx >= C && G < (1LL << 31) / 64, "esc_segment_pool_bwd: bad sizes");
+  const bool vec = (C % 4 == 0) && (ld_g % 4 == 0) && (ld_dx % 4 == 0) && esc::aligned16(g) && esc::aligned16(dx);
+  if (vec) esc::launch(-1, esc::segment_pool_bwd<4>, dim3((unsigned)esc::cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, g, ld_g, seg_ptr, (int)G, (int)C, mean, dx, ld_dx);
+  else     esc::launch(-1, esc::segment_pool_bwd<1>, dim3((unsigned)esc::cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, g, ld_g, seg_ptr, (int)G, (int)C, mean, dx, ld_dx);
+  ESC_CHECK_LAUNCH("esc_segment_pool_bwd");
   return ESC_OK;
 }
 

@@ -88,12 +88,10 @@ class GINEConv(torch.nn.Module):
 
 
 def global_add_pool(x, batch, size=None):
-    """segment sum by graph id (PyG global_add_pool).  Small [N,C]->[G,C]; torch index_add_."""
-    size = int(batch.max()) + 1 if size is None else size
-    return x.new_zeros((size, x.size(1))).index_add_(0, batch, x)
+    """PyG global_add_pool: segment sum by graph id (HIP segment_pool kernels)."""
+    return ops.segment_pool(x, batch, size, mean=False)
 
 
 def global_mean_pool(x, batch, size=None):
-    size = int(batch.max()) + 1 if size is None else size
-    cnt = torch.bincount(batch, minlength=size).clamp(min=1).to(x.dtype)
-    return global_add_pool(x, batch, size) / cnt.view(-1, 1)
+    """PyG global_mean_pool: segment sum / max(count, 1)."""
+    return ops.segment_pool(x, batch, size, mean=True)

@@ -236,3 +236,37 @@ class _L1Loss(Function):
 
 def l1_loss(pred, y, denom=None):
     return _L1Loss.apply(pred, y, denom)
+
+
+class _SegmentPool(Function):
+    """global_add_pool / global_mean_pool (run_graphcount.py:179, zinc_models.py:602) over a sorted batch vector."""
+
+    @staticmethod
+    def forward(ctx, x, seg_ptr, mean):
+        _dev(x)
+        x, ldx = _rows(x)
+        G, C = seg_ptr.numel() - 1, x.size(1)
+        out = torch.empty((G, C), dtype=torch.float32, device=x.device)
+        nv.call("esc_segment_pool_fwd", nv.ptr(x), ldx, nv.ptr(seg_ptr), G, C, int(mean), nv.ptr(out), C, nv.stream())
+        ctx.seg_ptr, ctx.mean, ctx.n = seg_ptr, bool(mean), x.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g, ldg = _rows(g)
+        G, C = g.shape
+        dx = torch.empty((ctx.n, C), dtype=torch.float32, device=g.device)
+        nv.call("esc_segment_pool_bwd", nv.ptr(g), ldg, nv.ptr(ctx.seg_ptr), G, C, int(ctx.mean), nv.ptr(dx), C,
+                nv.stream())
+        return dx, None, None
+
+
+def segment_pool(x, batch, size=None, mean=False):
+    """`batch` must be non-decreasing (Batch.from_data_list / the device collate produce it that way)."""
+    size = int(batch.max()) + 1 if size is None else int(size)
+    counts = torch.bincount(batch, minlength=size)
+    seg_ptr = torch.zeros(size + 1, dtype=torch.int32, device=batch.device)
+    seg_ptr[1:] = torch.cumsum(counts, 0)
+    if batch.numel() > 1 and not bool((batch[1:] >= batch[:-1]).all()):
+        raise ValueError("segment_pool: batch vector must be sorted")
+    return _SegmentPool.apply(x, seg_ptr, mean)

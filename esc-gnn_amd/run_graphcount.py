@@ -155,6 +155,7 @@ def main(argv=None):
     import torch.distributed as dist
 
     from . import ops
+    from .engine import StepEngine
     from .optim import FlatAdam, ReduceLROnPlateau
     from .parallel import broadcast_parameters, shard_slice
     from .store import DeviceGraphStore
@@ -223,6 +224,7 @@ def main(argv=None):
     optimizer = FlatAdam(model.parameters(), lr=args.lr)
     scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=args.lr_decay_factor, patience=args.patience,
                                   min_lr=0.00001)
+    engine = StepEngine(model)         # one native call per step; same parameters / .grad slots / BN buffers
     gen = torch.Generator().manual_seed(args.seed)
 
     def batches(store, shuffle):
@@ -238,11 +240,10 @@ def main(argv=None):
         model.train()
         loss_all = torch.zeros((), device=device)
         for data in batches(stores[0], True):
-            optimizer.zero_grad()
-            loss = ops.l1_loss(model(data), data.y.view(-1, 1))
-            loss.backward()
-            n_glob = optimizer.all_reduce_weighted(data.y.size(0)) if world > 1 else data.y.size(0)
-            loss_all += loss.detach() * data.y.size(0)
+            loss = engine.train_step(data)                # forward + L1Loss + backward (reference :494-503)
+            if world > 1:
+                optimizer.all_reduce_weighted(data.y.size(0))
+            loss_all += loss * data.y.size(0)
             optimizer.step()
         if world > 1:
             dist.all_reduce(loss_all)
@@ -253,7 +254,7 @@ def main(argv=None):
         err, num = torch.zeros((), device=device), 0
         with torch.no_grad():
             for data in batches(store, False):
-                y_hat = model(data)[:, 0]
+                y_hat = engine.predict(data)[:, 0]
                 err += torch.sum(torch.abs(y_hat - data.y))
                 num += data.y.size(0)
         tot = torch.stack([err, torch.tensor(float(num), device=device)])

@@ -70,6 +70,14 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                            int64_t ld_dx, int accumulate_dx /* dx += instead of = */, float* deps_part,
                            void* stream);
 
+/* graph readout (a-10): global_add_pool / global_mean_pool (run_graphcount.py:179; zinc_models.py:602) over the
+ * sorted node->graph vector given as segment pointers seg_ptr[G+1]; rows summed in node order (bit-identical to
+ * a sequential index_add_), mean divides by max(count,1).  Backward broadcasts g[graph]/count to the nodes. */
+int esc_segment_pool_fwd(const float* x, int64_t ld_x, const int32_t* seg_ptr, int64_t G, int64_t C,
+                         int mean, float* out, int64_t ld_out, void* stream);
+int esc_segment_pool_bwd(const float* g, int64_t ld_g, const int32_t* seg_ptr, int64_t G, int64_t C,
+                         int mean, float* dx, int64_t ld_dx, void* stream);
+
 /* deterministic sum of n floats (fp64 accumulation) -> out[0]; finishes deps from deps_part. */
 int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream);
 

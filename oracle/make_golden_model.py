@@ -28,14 +28,14 @@ REF_FILE = "/root/reference/run_graphcount.py"
 OUT = os.path.join(ROOT, "tests", "golden", "model_count.npz")
 
 
-def reference_class():
-    src = open(REF_FILE).read()
+def reference_class(ref_file=REF_FILE):
+    src = open(ref_file).read()
     tree = ast.parse(src)
     node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "NestedGIN_eff")
     ns = dict(torch=torch, F=F, Linear=torch.nn.Linear, Sequential=torch.nn.Sequential, ReLU=torch.nn.ReLU,
               BN=torch.nn.BatchNorm1d, Dropout=torch.nn.Dropout, GINEConv=rm.GINEConv,
               global_add_pool=rm.global_add_pool, global_mean_pool=rm.global_mean_pool)
-    exec(compile(ast.Module(body=[node], type_ignores=[]), REF_FILE, "exec"), ns)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), ref_file, "exec"), ns)
     return ns["NestedGIN_eff"]
 
 
@@ -123,5 +123,51 @@ def main():
     print("params L4 H256:", sum(p.numel() for p in big.parameters()))
 
 
+def main_sr():
+    """kernel/gin.py:200-379 (the run_sr.py / run_exp.py model): graph-level readout, log_softmax head."""
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "collate_mixed4.npz"))
+    b = {k[len("batch_"):]: torch.tensor(g[k]) for k in g.files if k.startswith("batch_")}
+    L, H, NC = 3, 16, 3
+
+    class DS(object):
+        num_features, num_classes = 10, NC
+    torch.manual_seed(4321)
+    Ref = reference_class("/root/reference/kernel/gin.py")
+    ref = Ref(DS, L, H, use_rd=False, graph_pred=True, dropout=0, use_cycle=False)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if p.dim() == 1 and "bias" not in name:
+                p.add_(0.1 * torch.randn_like(p))
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    mine = rm.NestedGINEffSRRef(10, NC, L, H, graph_pred=True, dropout=0.0, use_cycle=False)
+    assert list(mine.state_dict().keys()) == list(sd0.keys())
+    mine.load_state_dict(sd0)
+    x = torch.randn(b["x"].shape[0], 10)                 # non-constant node features
+    label = torch.tensor([0, 2, 1, 1])
+    res = []
+    for m, call in ((ref, lambda m: m(Bag(x=x, edge_index=b["edge_index"], batch=b["batch"], pos_enc=b["pos_enc"],
+                                         pos_index=b["pos_index"], pos_batch=b["pos_batch"]))),
+                    (mine, lambda m: m(x, b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"]))):
+        m.train()
+        out = call(m)
+        loss = F.nll_loss(out, label)
+        loss.backward()
+        res.append((out.detach(), loss.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    out = {"keys": np.array(list(sd0.keys())), "x": x.numpy(), "label": label.numpy(), "logp": res[0][0].numpy(),
+           "loss": res[0][1].numpy(), "layers": np.int64(L), "hidden": np.int64(H), "classes": np.int64(NC)}
+    for k, v in sd0.items():
+        out["param/" + k] = v.numpy()
+    for k, v in res[0][2].items():
+        out["grad/" + k] = v.numpy()
+    path = os.path.join(ROOT, "tests", "golden", "model_sr.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; loss", float(res[0][1]))
+
+
 if __name__ == "__main__":
     main()
+    main_sr()

@@ -113,6 +113,42 @@ class NestedGINEffRef(torch.nn.Module):
         return (o, cat) if return_embeddings else o
 
 
+class NestedGINEffSRRef(torch.nn.Module):
+    """kernel/gin.py:200-379 composition (run_sr.py / run_exp.py): no x_embedding, lin1 over L*H, dropout before
+    the last ReLU, mean-pool readout, log_softmax head unless use_cycle.  Same state_dict keys."""
+
+    def __init__(self, num_features, num_classes, num_layers, hidden, graph_pred=True, dropout=0.0, use_cycle=False):
+        super().__init__()
+        self.graph_pred, self.dropout, self.use_cycle = graph_pred, dropout, use_cycle
+        self.z_initial = torch.nn.Embedding(1800, hidden)
+        self.z_embedding = Sequential(Dropout(dropout), BatchNorm1d(hidden), ReLU(), Linear(hidden, hidden),
+                                      Dropout(dropout), BatchNorm1d(hidden), ReLU())
+        self.conv1 = GINEConv(_mlp(num_features, hidden, dropout), train_eps=True, edge_dim=hidden)
+        self.convs = torch.nn.ModuleList(
+            [GINEConv(_mlp(hidden, hidden, dropout), train_eps=True, edge_dim=hidden) for _ in range(num_layers - 1)])
+        self.lin1 = Linear(num_layers * hidden, hidden)
+        self.bn_lin1 = BatchNorm1d(hidden, eps=1e-5, momentum=0.1)
+        self.lin2 = Linear(hidden, 1 if use_cycle else num_classes)
+
+    def forward(self, x, edge_index, pos_enc, pos_index, pos_batch, batch):
+        z = global_add_pool(self.z_initial.weight[pos_index] * pos_enc.view(-1, 1), pos_batch)
+        z = self.z_embedding(z)
+        h = self.conv1(x, edge_index, z)
+        xs = [h]
+        for conv in self.convs:
+            h = conv(h, edge_index, z)
+            xs.append(h)
+        o = torch.cat(xs, dim=1)
+        if self.graph_pred:
+            o = global_mean_pool(o, batch)
+        o = self.lin1(o)
+        if o.size(0) > 1:
+            o = self.bn_lin1(o)
+        o = F.relu(F.dropout(o, p=self.dropout, training=self.training))
+        o = self.lin2(o)
+        return o if self.use_cycle else F.log_softmax(o, dim=-1)
+
+
 def train_step(model, optimizer, b):
     """One optimisation step as run_graphcount.py:494-505 (L1 loss, mean over nodes)."""
     optimizer.zero_grad()

@@ -179,3 +179,30 @@ def test_step_engine_matches_oracle_and_autograd(L, H, tag):
         want = mine(E.Data(**{k: v.clone() for k, v in b.items()}))
     got = eng.predict(E.Data(**{k: v.clone().to("cuda:0") for k, v in b.items()}))
     _close(got, want.cpu(), "engine predict vs module eval")
+
+
+def test_sr_variant_against_reference_golden():
+    """esc_gnn_amd.kernel_gin.NestedGIN_eff (graph readout via the HIP segment-pool kernels, log_softmax head)
+    against tests/golden/model_sr.npz (reference kernel/gin.py class body on the oracle primitives)."""
+    require_gpu()
+    import esc_gnn_amd as E
+    from esc_gnn_amd.kernel_gin import NestedGIN_eff as SR
+    z = np.load(os.path.join(GOLDEN, "model_sr.npz"))
+
+    class DS(object):
+        num_features, num_classes = 10, int(z["classes"])
+    m = SR(DS, int(z["layers"]), int(z["hidden"]), use_rd=False, graph_pred=True, dropout=0, use_cycle=False)
+    keys = [str(k) for k in z["keys"]]
+    assert list(m.state_dict().keys()) == keys
+    m.load_state_dict({k: torch.tensor(z["param/" + k]) for k in keys})
+    m = m.to("cuda:0").train()
+    _, b, _ = load_collate("mixed4")
+    data = E.Data(**{k: torch.tensor(v) for k, v in b.items()})
+    data.x = torch.tensor(z["x"])
+    out = m(data)
+    loss = torch.nn.functional.nll_loss(out, torch.tensor(z["label"]).to("cuda:0"))
+    loss.backward()
+    _close(out, torch.tensor(z["logp"]), "log-probabilities")
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5
+    for n, p in m.named_parameters():
+        _close(p.grad, torch.tensor(z["grad/" + n]), "grad " + n, tol=1e-4)

@@ -177,3 +177,25 @@ def test_bad_arguments_raise(E):
     with pytest.raises(IndexError):
         E.BatchPlan.from_tensors(b["edge_index"].to(dev), b["x"].shape[0], b["pos_enc"].to(dev),
                                  (b["pos_index"] + 1800).to(dev), b["pos_batch"].to(dev))
+
+
+@pytest.mark.parametrize("C,mean", [(256, False), (1280, True), (10, True)])
+def test_segment_pool(E, C, mean):
+    torch.manual_seed(C)
+    dev = torch.device("cuda:0")
+    b = _batch("mixed4")
+    x = torch.randn(b["x"].shape[0], C)
+    torch.set_num_threads(1)
+    ref = (rm.global_mean_pool if mean else rm.global_add_pool)(x, b["batch"])
+    xd = x.to(dev).requires_grad_(True)
+    out = (E.global_mean_pool if mean else E.global_add_pool)(xd, b["batch"].to(dev))
+    if mean:
+        assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    else:
+        assert torch.equal(out.cpu(), ref)
+    g = torch.randn_like(ref)
+    out.backward(g.to(dev))
+    x64 = x.double().requires_grad_(True)
+    r64 = (rm.global_mean_pool if mean else rm.global_add_pool)(x64, b["batch"])
+    r64.backward(g.double())
+    _chk(xd.grad, x64.grad, "pool dx")

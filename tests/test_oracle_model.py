@@ -66,3 +66,19 @@ def test_primitives_against_fp64_loops():
     for k in range(E):
         ref[int(ei[1, k])] += np.maximum(x[int(ei[0, k])].double().numpy() + e[k], 0)
     assert np.allclose(out.numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_sr_variant_matches_reference_composition():
+    """kernel/gin.py:200-379 (run_sr / run_exp model) golden produced from the reference class body."""
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(GOLDEN, "model_sr.npz"))
+    m = rm.NestedGINEffSRRef(10, int(z["classes"]), int(z["layers"]), int(z["hidden"]))
+    keys = [str(k) for k in z["keys"]]
+    assert list(m.state_dict().keys()) == keys
+    m.load_state_dict({k: torch.tensor(z["param/" + k]) for k in keys})
+    _, b, _ = load_collate("mixed4")
+    b = {k: torch.tensor(v) for k, v in b.items()}
+    m.train()
+    out = m(torch.tensor(z["x"]), b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
+    loss = torch.nn.functional.nll_loss(out, torch.tensor(z["label"]))
+    assert torch.equal(out.detach(), torch.tensor(z["logp"])) and torch.equal(loss.detach(), torch.tensor(z["loss"]))
