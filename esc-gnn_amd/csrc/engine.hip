@@ -115,14 +115,13 @@ static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const 
   const int64_t H = y.H;
   ESC_TRY(esc_bn_bwd(w.Y1, H, out, ld_out, dOut, ld_dout, M, H, w.b1.mean, w.b1.invstd, p.bn1.gamma, p.bn1.beta, 1,
                      y.dT1, H, p.bn1.dgamma, p.bn1.dbeta, y.bn_scratch, c.s));
-  ESC_TRY(esc_linear_bwd_weight(y.dT1, H, w.Y0, H, w.b0.scale, w.b0.shift, M, H, H, p.lin1.dw, H, p.lin1.db, y.slabs, c.s));
-  ESC_TRY(esc_linear_bwd_input(y.dT1, H, p.lin1.w, H, M, H, H, y.dT2, H, 0, c.s));
+  ESC_TRY(esc_linear_bwd_both(y.dT1, H, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1.w, H, M, H, H, y.dT2, H, 0, p.lin1.dw, H,
+                              p.lin1.db, y.slabs, c.s));
   ESC_TRY(esc_bn_bwd(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, 1,
                      y.dT2, H, p.bn0.dgamma, p.bn0.dbeta, y.bn_scratch, c.s));
   const int64_t K = p.lin0.in_dim;
-  ESC_TRY(esc_linear_bwd_weight(y.dT2, H, A, ld_a, nullptr, nullptr, M, H, K, p.lin0.dw, K, p.lin0.db, y.slabs, c.s));
-  if (dA) ESC_TRY(esc_linear_bwd_input(y.dT2, H, p.lin0.w, K, M, H, K, dA, ld_da, 0, c.s));
-  return ESC_OK;
+  return esc_linear_bwd_both(y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0.w, K, M, H, K, dA, ld_da, 0, p.lin0.dw, K,
+                             p.lin0.db, y.slabs, c.s);
 }
 
 static int forward(const Ctx& c) {
@@ -163,8 +162,8 @@ static int backward(const Ctx& c) {
   ESC_TRY(esc_linear_bwd_input(y.dpred, 1, m->lin2.w, H, N, 1, H, y.dAl, H, 0, c.s));
   ESC_TRY(esc_bn_bwd(y.Yl, H, nullptr, 0, y.dAl, H, N, H, y.bl.mean, y.bl.invstd, m->bn_lin1.gamma, m->bn_lin1.beta, 1,
                      y.dAl, H, m->bn_lin1.dgamma, m->bn_lin1.dbeta, y.bn_scratch, c.s));
-  ESC_TRY(esc_linear_bwd_weight(y.dAl, H, y.cat, W, nullptr, nullptr, N, H, W, m->lin1.dw, W, m->lin1.db, y.slabs, c.s));
-  ESC_TRY(esc_linear_bwd_input(y.dAl, H, m->lin1.w, W, N, H, W, y.dcat, W, 0, c.s));
+  ESC_TRY(esc_linear_bwd_both(y.dAl, H, y.cat, W, nullptr, nullptr, m->lin1.w, W, N, H, W, y.dcat, W, 0, m->lin1.dw, W,
+                              m->lin1.db, y.slabs, c.s));
   // GINE layers, last to first
   for (int l = (int)L - 1; l >= 0; --l) {
     const esc_conv_t& cv = m->conv[l];
@@ -177,16 +176,16 @@ static int backward(const Ctx& c) {
     ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
                                    y.d_e, C, dx, W, 1, y.deps_part, c.s));
     ESC_TRY(esc_reduce_sum(y.deps_part, N, cv.deps, c.s));
-    ESC_TRY(esc_linear_bwd_weight(y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, E, C, H, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
-    ESC_TRY(esc_linear_bwd_input(y.d_e, C, cv.lin.w, H, E, C, H, y.dZemb, H, l == (int)L - 1 ? 0 : 1, c.s));
+    ESC_TRY(esc_linear_bwd_both(y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin.w, H, E, C, H, y.dZemb, H,
+                                l == (int)L - 1 ? 0 : 1, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
   }
   // x_embedding (input x needs no gradient)
   ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
   // z_embedding + bag
   ESC_TRY(esc_bn_bwd(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma, m->zbn1.beta, 1,
                      y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, y.bn_scratch, c.s));
-  ESC_TRY(esc_linear_bwd_weight(y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, E, H, H, m->zlin.dw, H, m->zlin.db, y.slabs, c.s));
-  ESC_TRY(esc_linear_bwd_input(y.dZemb, H, m->zlin.w, H, E, H, H, y.dAz, H, 0, c.s));
+  ESC_TRY(esc_linear_bwd_both(y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin.w, H, E, H, H, y.dAz, H, 0, m->zlin.dw,
+                              H, m->zlin.db, y.slabs, c.s));
   ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, y.bn_scratch, c.s));
   return esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,

@@ -228,19 +228,18 @@ struct GemmArgs {
 };
 
 template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restrict__ lds, int bx, int by, int bz) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NT = TN / 32;
   static_assert(MT >= 1 && NT >= 1, "wave tile must hold at least one 32x32 block");
   using ATile = typename std::conditional<A_KC, KContigTile<BM, BK>, RedMajorTile<BM, BK>>::type;
   using BTile = typename std::conditional<B_KC, KContigTile<BN, BK>, RedMajorTile<BN, BK>>::type;
-  constexpr int STAGE = ATile::FLOATS + BTile::FLOATS;   // one K-step of A then B
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 stages
+  constexpr int STAGE = ATile::FLOATS + BTile::FLOATS;   // one K-step of A then B (LDS holds 2 stages)
 
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
-  const int split = blockIdx.z;
+  const int m0 = by * BM;
+  const int n0 = bx * BN;
+  const int split = bz;
   const int red0 = split * g.red_per_split;
   const int red1 = min(g.red, red0 + g.red_per_split);
   const int wave = threadIdx.x >> 6;
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
     const float* a_l = lds + cur * STAGE;
     const float* b_l = a_l + ATile::FLOATS;
     if constexpr (DB) {   // column sums of the reduction-major A' tile (bias gradient), block column 0 only
-      if (blockIdx.x == 0 && threadIdx.x < BM) {
+      if (bx == 0 && threadIdx.x < BM) {
 #pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) dbsum += a_l[kk * ATile::LD + threadIdx.x];
       }
@@ -381,8 +380,32 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
       }
     }
   if constexpr (DB) {
-    if (blockIdx.x == 0 && threadIdx.x < BM && m0 + (int)threadIdx.x < g.rowsC)
+    if (bx == 0 && threadIdx.x < BM && m0 + (int)threadIdx.x < g.rowsC)
       g.db_part[(size_t)split * g.rowsC + m0 + threadIdx.x] = dbsum;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  gemm_tile_body<BM, BN, WM, WN, BK, A_KC, B_KC, PRO, DB>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Backward of one Linear in ONE launch: the first gx workgroups compute dX = dY*W tiles, the rest the
+// split-M dW = dY^T*act(X) slabs.  Both stream the same dY; fusing them removes a launch boundary and lets
+// the two under-filled grids of the node-sized layers (152 + 304 workgroups) share the chip.
+struct DualArgs { GemmArgs dx; GemmArgs dw; int dx_nx, dx_ny, dw_nx, dw_ny, dw_nz; };
+template <int BM, int BN, int BK, bool PRO>
+__global__ __launch_bounds__(256) void gemm_bwd_dual_kernel(DualArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.x;
+  const int n_dx = a.dx_nx * a.dx_ny;
+  if (b < n_dx) {
+    gemm_tile_body<BM, BN, 2, 2, BK, true, false, false, false>(a.dx, lds, b % a.dx_nx, b / a.dx_nx, 0);
+  } else {
+    const int r = b - n_dx;
+    const int per = a.dw_nx * a.dw_ny;
+    gemm_tile_body<BM, BN, 2, 2, BK, false, false, PRO, true>(a.dw, lds, (r % per) % a.dw_nx, (r % per) / a.dw_nx, r / per);
   }
 }
 
@@ -525,11 +548,17 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
   return ESC_OK;
 }
 
+static void wgrad_plan_tile(int64_t M, int64_t N, int64_t K, int bm, int bn, int bk, int* splits, int* per_split);
+
 static void wgrad_plan(int64_t M, int64_t N, int64_t K, int* splits, int* per_split) {
-  // enough splits along M for ~KNOB_DW_BLOCKS workgroups, each >= 128 rows deep (fixed by the shape
-  // only, so scratch sizing and the launch agree)
   int bm, bn, bk;
   tile_dims(g_knob[KNOB_DW_TILE], &bm, &bn, &bk);
+  wgrad_plan_tile(M, N, K, bm, bn, bk, splits, per_split);
+}
+
+static void wgrad_plan_tile(int64_t M, int64_t N, int64_t K, int bm, int bn, int bk, int* splits, int* per_split) {
+  // enough splits along M for ~KNOB_DW_BLOCKS workgroups, each >= 128 rows deep (fixed by the shape
+  // only, so scratch sizing and the launch agree)
   const int64_t tiles = cdiv(N, bm) * cdiv(K, bn);
   int64_t want = cdiv(g_knob[KNOB_DW_BLOCKS], tiles);
   int64_t max_splits = cdiv(M, g_knob[KNOB_DW_MIN_ROWS] < 128 ? 128 : g_knob[KNOB_DW_MIN_ROWS]);
@@ -574,6 +603,65 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
   esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
               splits, (int)K, dW, ld_dw, g.db_part, (int)N, db);
   ESC_CHECK_LAUNCH("esc_linear_bwd_weight.reduce");
+  return ESC_OK;
+}
+
+}  // extern "C"
+
+template <int BK, bool PRO>
+static void launch_dual(const DualArgs& a, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)(KContigTile<64, BK>::FLOATS + RedMajorTile<64, BK>::FLOATS) * sizeof(float);
+  constexpr size_t lds2 = 2 * (size_t)(2 * RedMajorTile<64, BK>::FLOATS) * sizeof(float);
+  constexpr size_t need = lds > lds2 ? lds : lds2;
+  auto kern = gemm_bwd_dual_kernel<64, 64, BK, PRO>;
+  if (need > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); raised = true; }
+  }
+  const unsigned blocks = (unsigned)(a.dx_nx * a.dx_ny + a.dw_nx * a.dw_ny * a.dw_nz);
+  esc::launch(ESC_K_LINEAR, kern, dim3(blocks), dim3(256), need, s, a);
+}
+
+extern "C" {
+
+int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
+                        const float* in_shift, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K,
+                        float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw, float* db,
+                        float* slabs, void* stream) {
+  ESC_REQUIRE(dY && X && W && dW && slabs, "esc_linear_bwd_both: null pointer");
+  if (dX == nullptr || N <= 32 || K <= 32) {             // narrow shapes keep their dedicated tiles
+    int rc = esc_linear_bwd_weight(dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, dW, ld_dw, db, slabs, stream);
+    if (rc || dX == nullptr) return rc;
+    return esc_linear_bwd_input(dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate, stream);
+  }
+  ESC_REQUIRE(M > 0 && ld_dy >= N && ld_x >= K && ld_w >= K && ld_dx >= K && ld_dw >= K, "esc_linear_bwd_both: bad sizes");
+  ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_bwd_both: in_scale/in_shift must come together");
+  ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_both: dimension too large");
+  hipStream_t s = (hipStream_t)stream;
+  const int bk = M >= 8192 ? 32 : 64;
+  int splits, per;
+  wgrad_plan_tile(M, N, K, 64, 64, bk, &splits, &per);
+  DualArgs a{};
+  GemmArgs& g = a.dx;
+  g.A = dY; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.C = dX; g.ldc = ld_dx;
+  g.rowsC = (int)M; g.colsC = (int)K; g.red = (int)N; g.red_per_split = (int)N; g.accumulate = accumulate;
+  g.a_vec = vec_ok(dY, ld_dy); g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
+  GemmArgs& w = a.dw;
+  w.A = dY; w.lda = ld_dy; w.B = X; w.ldb = ld_x; w.C = slabs; w.ldc = K;
+  w.pro_scale = in_scale; w.pro_shift = in_shift; w.db_part = slabs + (size_t)splits * N * K;
+  w.rowsC = (int)N; w.colsC = (int)K; w.red = (int)M; w.red_per_split = per; w.accumulate = 0;
+  w.a_vec = vec_ok(dY, ld_dy);
+  w.b_vec = vec_ok(X, ld_x) && (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
+  w.c_slab = 1;
+  a.dx_nx = (int)cdiv(K, 64); a.dx_ny = (int)cdiv(M, 64);
+  a.dw_nx = (int)cdiv(K, 64); a.dw_ny = (int)cdiv(N, 64); a.dw_nz = splits;
+  if (bk == 32) { if (in_scale) launch_dual<32, true>(a, s); else launch_dual<32, false>(a, s); }
+  else          { if (in_scale) launch_dual<64, true>(a, s); else launch_dual<64, false>(a, s); }
+  ESC_CHECK_LAUNCH("esc_linear_bwd_both.tiles");
+  const int64_t n = N * K;
+  esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+              splits, (int)K, dW, ld_dw, w.db_part, (int)N, db);
+  ESC_CHECK_LAUNCH("esc_linear_bwd_both.reduce");
   return ESC_OK;
 }
 

@@ -109,6 +109,13 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
                           int64_t K, float* dW, int64_t ld_dw, float* db, float* slabs,
                           void* stream);
 
+/* both gradients of one Linear in ONE launch (dX tiles + split-M dW slabs share the dY stream), then the
+ * ordered slab reduce.  dX may be NULL (weight gradient only).  Same scratch as esc_linear_bwd_weight. */
+int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x,
+                        const float* in_scale, const float* in_shift, const float* W, int64_t ld_w,
+                        int64_t M, int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate,
+                        float* dW, int64_t ld_dw, float* db, float* slabs, void* stream);
+
 /* ---- BatchNorm1d (training statistics) + ReLU, torch.nn.BatchNorm1d call sites
  * run_graphcount.py:55-60,66-72,80-87,115 --------------------------------------------------
  * stats: mean[C], invstd[C] of X[M,C] (biased variance, eps), optional running-stat update
