@@ -55,6 +55,7 @@ SIGNATURES = {
     "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, I64, P, P, P, P],
     "esc_affine_act": [P, I64, I64, I64, P, P, I32, P, I64, P],
     "esc_bn_eval_coef": [P, P, P, P, F32, I64, P, P, P],
+    "esc_engine_set_side_stream": [I32],
     "esc_engine_workspace_floats": [P, I64, I64, I64],
     "esc_engine_train_step": [P, P, P, I64, P, P, P],
     "esc_engine_predict": [P, P, P, P, P],

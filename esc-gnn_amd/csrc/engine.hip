@@ -38,6 +38,8 @@ struct Layout {
   // backward scratch
   float *dcat, *dAl, *dT1, *dT2, *dagg, *d_e, *dZemb, *dAz, *deps_part;
   float *bn_scratch, *bag_scratch, *slabs;
+  // private scratch of the x_embedding branch (runs on a side stream next to the z/conv chain)
+  float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
   int64_t total;
 };
 
@@ -60,7 +62,10 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   y.cat = a.take(N * y.W); y.Yl = a.take(N * H); y.bl = take_bn(a, H);
   y.pred = a.take(N); y.dpred = a.take(N);
   y.bn_scratch = a.take(esc_bn_scratch(H));
+  y.bn_scratch_x = a.take(esc_bn_scratch(H));
   if (train) {
+    y.dT1x = a.take(N * H); y.dT2x = a.take(N * H);
+    y.slabs_x = a.take(esc_linear_bwd_weight_scratch(N, H, H));
     y.dcat = a.take(N * y.W); y.dAl = a.take(N * H); y.dT1 = a.take(N * H); y.dT2 = a.take(N * H);
     y.dagg = a.take(N * H); y.d_e = a.take(E * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
     y.deps_part = a.take(N);
@@ -87,6 +92,36 @@ struct Ctx {
   void* s;
   bool train;
 };
+
+// The x_embedding MLP depends only on x (forward) / on d(cat)[:, 0:H] (backward): five to eight small,
+// latency-bound launches that overlap perfectly with the edge-sized work of the main chain.  They run on a
+// second HIP stream with their own scratch, forked and joined with events (a capturable fork/join).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr;
+  bool ok = false;
+};
+static int g_use_side_stream = 0;     // esc_engine_set_side_stream(); measured neutral-to-negative on MI355X r01
+
+static SideStream& side_stream() {
+  static thread_local SideStream ss;
+  static thread_local SideStream off;   // ok == false
+  if (!g_use_side_stream) return off;
+  if (!ss.ok && ss.stream == nullptr) {
+    bool good = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess;
+    hipEvent_t* evs[4] = {&ss.fork_f, &ss.join_f, &ss.fork_b, &ss.join_b};
+    for (auto e : evs) good = good && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    ss.ok = good;
+  }
+  return ss;
+}
+static Ctx side_ctx(const Ctx& c, hipStream_t side) {
+  Ctx x = c;
+  x.s = side;
+  x.y.bn_scratch = c.y.bn_scratch_x;
+  x.y.dT1 = c.y.dT1x; x.y.dT2 = c.y.dT2x; x.y.slabs = c.y.slabs_x;
+  return x;
+}
 
 static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const esc_bn_t& bn, const BnWs& w) {
   const int64_t C = c.y.H;
@@ -134,8 +169,19 @@ static int forward(const Ctx& c) {
   ESC_TRY(bn_coeffs(c, y.Zb, H, E, m->zbn0, y.zb0));
   ESC_TRY(esc_linear_fwd(y.Zb, H, m->zlin.w, H, m->zlin.b, y.zb0.scale, y.zb0.shift, E, H, H, y.Yz, H, nullptr, c.s));
   ESC_TRY(bn_coeffs(c, y.Yz, H, E, m->zbn1, y.zb1));                      // z_emb = relu(Yz*scale+shift), virtual
-  // xs[0] = x_embedding(x) (reference :166)
-  ESC_TRY(mlp_forward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W));
+  // xs[0] = x_embedding(x) (reference :166) — side stream
+  SideStream& ss = side_stream();
+  if (ss.ok) {
+    if (hipEventRecord(ss.fork_f, (hipStream_t)c.s) != hipSuccess || hipStreamWaitEvent(ss.stream, ss.fork_f, 0) != hipSuccess) {
+      set_error("esc_engine: side-stream fork failed");
+      return ESC_ELAUNCH;
+    }
+    const Ctx cx = side_ctx(c, ss.stream);
+    ESC_TRY(mlp_forward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W));
+    (void)hipEventRecord(ss.join_f, ss.stream);
+  } else {
+    ESC_TRY(mlp_forward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W));
+  }
   // GINE layers (reference :161, :167-175): xs[l+1] -> cat[:, (l+1)H : (l+2)H]
   for (int l = 0; l < L; ++l) {
     const esc_conv_t& cv = m->conv[l];
@@ -146,7 +192,11 @@ static int forward(const Ctx& c) {
     ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
     ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W));
   }
-  // readout (reference :183-189)
+  // readout (reference :183-189) needs every slice of cat, including the side stream's
+  if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_f, 0) != hipSuccess) {
+    set_error("esc_engine: side-stream join failed");
+    return ESC_ELAUNCH;
+  }
   ESC_TRY(esc_linear_fwd(y.cat, W, m->lin1.w, W, m->lin1.b, nullptr, nullptr, N, H, W, y.Yl, H, nullptr, c.s));
   ESC_TRY(bn_coeffs(c, y.Yl, H, N, m->bn_lin1, y.bl));
   return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
@@ -164,6 +214,17 @@ static int backward(const Ctx& c) {
                      y.dAl, H, m->bn_lin1.dgamma, m->bn_lin1.dbeta, y.bn_scratch, c.s));
   ESC_TRY(esc_linear_bwd_both(y.dAl, H, y.cat, W, nullptr, nullptr, m->lin1.w, W, N, H, W, y.dcat, W, 0, m->lin1.dw, W,
                               m->lin1.db, y.slabs, c.s));
+  // x_embedding backward (input x needs no gradient): only reads d(cat)[:, 0:H] -> side stream
+  SideStream& ss = side_stream();
+  if (ss.ok) {
+    if (hipEventRecord(ss.fork_b, (hipStream_t)c.s) != hipSuccess || hipStreamWaitEvent(ss.stream, ss.fork_b, 0) != hipSuccess) {
+      set_error("esc_engine: side-stream fork failed");
+      return ESC_ELAUNCH;
+    }
+    const Ctx cx = side_ctx(c, ss.stream);
+    ESC_TRY(mlp_backward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
+    (void)hipEventRecord(ss.join_b, ss.stream);
+  }
   // GINE layers, last to first
   for (int l = (int)L - 1; l >= 0; --l) {
     const esc_conv_t& cv = m->conv[l];
@@ -179,8 +240,7 @@ static int backward(const Ctx& c) {
     ESC_TRY(esc_linear_bwd_both(y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin.w, H, E, C, H, y.dZemb, H,
                                 l == (int)L - 1 ? 0 : 1, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
   }
-  // x_embedding (input x needs no gradient)
-  ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
+  if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
   // z_embedding + bag
   ESC_TRY(esc_bn_bwd(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma, m->zbn1.beta, 1,
                      y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, y.bn_scratch, c.s));
@@ -188,8 +248,13 @@ static int backward(const Ctx& c) {
                               H, m->zlin.db, y.slabs, c.s));
   ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, y.bn_scratch, c.s));
-  return esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
-                           y.bag_scratch, c.s);
+  ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
+                            y.bag_scratch, c.s));
+  if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_b, 0) != hipSuccess) {
+    set_error("esc_engine: side-stream join failed");
+    return ESC_ELAUNCH;
+  }
+  return ESC_OK;
 }
 
 static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* ws, bool train) {
@@ -207,6 +272,11 @@ static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* w
 using namespace esc;
 
 extern "C" {
+
+int esc_engine_set_side_stream(int on) {
+  g_use_side_stream = on != 0;
+  return ESC_OK;
+}
 
 int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z) {
   if (!m || N < 0 || E < 0 || Z < 0) return -1;

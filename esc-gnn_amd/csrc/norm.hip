@@ -10,7 +10,26 @@
 
 namespace esc {
 
-constexpr int NORM_ROWBLOCKS = 64;          // grid.y; x4 waves => 256 row slots
+constexpr int NORM_ROWBLOCKS = 64;
+
+// fused activation after the affine: 0 none, 1 ReLU, 2 ELU(alpha=1) (zinc_models.py:513-522 uses ELU)
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return v > 0.f ? v : expm1f(v);
+  return v;
+}
+// d act / d v expressed through the forward OUTPUT y (relu: [y>0]; elu: y>0 ? 1 : y+1)
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  if (act == 1) return y > 0.f ? 1.f : 0.f;
+  if (act == 2) return y > 0.f ? 1.f : y + 1.f;
+  return 1.f;
+}
+// ... or through the pre-activation v when the output was never materialised
+__device__ __forceinline__ float act_grad_from_pre(float v, int act) {
+  if (act == 1) return v > 0.f ? 1.f : 0.f;
+  if (act == 2) return v > 0.f ? 1.f : expf(v);
+  return 1.f;
+}          // grid.y; x4 waves => 256 row slots
 
 // slot p owns rows p, p+P, p+2P, ...   partial[(p*C + c)] = {mean, M2}
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ X, int64_t ld, int M, int C,
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     for (int t = 0; t < VEC; ++t) {
       float v = (xv[t] - mean[c + t]) * invstd[c + t];
       v = fmaf(v, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f);
-      yv[t] = relu ? fmaxf(v, 0.f) : v;
+      yv[t] = act_fwd(v, relu);
     }
     if constexpr (VEC == 4) {
       *reinterpret_cast<float4*>(Y + r * ldy + c) = make_float4(yv[0], yv[1], yv[2], yv[3]);
@@ -141,9 +160,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   for (int r = slot; r < M; r += P) {
     float g = dY[(size_t)r * ldg + c];
     const float xh = (X[(size_t)r * ldx + c] - mu) * is;
-    if (relu) {   // forward output (if kept) or its recomputation decides the ReLU mask
-      const float yv = Y ? Y[(size_t)r * ldy + c] : fmaf(xh, ga, be);
-      if (!(yv > 0.f)) g = 0.f;
+    if (relu) {   // activation derivative from the forward output (if kept) or from the recomputed pre-activation
+      g *= Y ? act_grad_from_out(Y[(size_t)r * ldy + c], relu) : act_grad_from_pre(fmaf(xh, ga, be), relu);
     }
     s1 += g;
     s2 = fmaf(g, xh, s2);
@@ -207,8 +225,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int t = 0; t < VEC; ++t) {
       const float is = invstd[c + t];
       const float xh = (xv[t] - mean[c + t]) * is;
-      if (relu && !Y) yv[t] = fmaf(xh, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f);
-      const float g = (relu && !(yv[t] > 0.f)) ? 0.f : gv[t];
+      float g = gv[t];
+      if (relu) g *= Y ? act_grad_from_out(yv[t], relu)
+                       : act_grad_from_pre(fmaf(xh, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f), relu);
       const float2 k = coef[c + t];
       ov[t] = (gamma ? gamma[c + t] : 1.f) * is * (g - k.x - xh * k.y);
     }
@@ -236,11 +255,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       const float4 s4 = *reinterpret_cast<const float4*>(scale + c);
       const float4 h4 = *reinterpret_cast<const float4*>(shift + c);
       float4 o = make_float4(fmaf(q.x, s4.x, h4.x), fmaf(q.y, s4.y, h4.y), fmaf(q.z, s4.z, h4.z), fmaf(q.w, s4.w, h4.w));
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      o.x = act_fwd(o.x, relu); o.y = act_fwd(o.y, relu); o.z = act_fwd(o.z, relu); o.w = act_fwd(o.w, relu);
       *reinterpret_cast<float4*>(Y + r * ldy + c) = o;
     } else {
-      const float o = fmaf(X[r * ldx + c], scale[c], shift[c]);
-      Y[r * ldy + c] = relu ? fmaxf(o, 0.f) : o;
+      Y[r * ldy + c] = act_fwd(fmaf(X[r * ldx + c], scale[c], shift[c]), relu);
     }
   }
 }

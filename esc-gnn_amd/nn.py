@@ -23,9 +23,12 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
     `fuse_relu=True` also applies the ReLU that follows it in the reference's Sequential (the
     ReLU module stays in place as `AbsorbedReLU` so the child indices / checkpoint keys match)."""
 
+    ACT = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "elu": 2}
+
     def __init__(self, num_features, eps=1e-5, momentum=0.1, fuse_relu=False):
+        """fuse_relu: False/None | True/'relu' | 'elu' — the activation module that follows in the reference."""
         super().__init__(num_features, eps=eps, momentum=momentum)
-        self.fuse_relu = fuse_relu
+        self.fuse_relu = self.ACT[fuse_relu]
 
     def forward(self, x):
         if x.dim() != 2:
@@ -38,7 +41,7 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             y = torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
                                                False, 0.0, self.eps)
-            return torch.relu(y) if self.fuse_relu else y
+            return torch.relu(y) if self.fuse_relu == 1 else (torch.nn.functional.elu(y) if self.fuse_relu == 2 else y)
         return ops.bn_eval_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                self.fuse_relu)
 
@@ -48,6 +51,20 @@ class AbsorbedReLU(torch.nn.ReLU):
 
     def forward(self, x):
         return x
+
+
+class AbsorbedELU(torch.nn.ELU):
+    """Placeholder for an ELU fused into the preceding BatchNorm1d(fuse_relu='elu')."""
+
+    def forward(self, x):
+        return x
+
+
+class Embedding(torch.nn.Embedding):
+    """torch.nn.Embedding whose lookup and gradient run through the ESC bag kernels (one entry of weight 1 per row)."""
+
+    def forward(self, index):
+        return ops.embedding(self.weight, index)
 
 
 class GINEConv(torch.nn.Module):

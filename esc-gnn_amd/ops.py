@@ -177,7 +177,7 @@ class _BatchNormAct(Function):
         nv.call("esc_bn_apply", nv.ptr(x), ldx, M, C, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
                 int(relu), nv.ptr(y), C, s)
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
-        ctx.relu, ctx.scratch = bool(relu), scratch
+        ctx.relu, ctx.scratch = int(relu), scratch        # 0 none, 1 relu, 2 elu
         return y
 
     @staticmethod
@@ -270,3 +270,46 @@ def segment_pool(x, batch, size=None, mean=False):
     if batch.numel() > 1 and not bool((batch[1:] >= batch[:-1]).all()):
         raise ValueError("segment_pool: batch vector must be sorted")
     return _SegmentPool.apply(x, seg_ptr, mean)
+
+
+class _Embedding(Function):
+    """weight[index] via esc_bag_fwd with unit counts (exact: 0 + w*1); gradient via the CSC segmented sum."""
+
+    @staticmethod
+    def forward(ctx, weight, index):
+        _dev(weight)
+        weight = weight.contiguous()
+        idx = index.reshape(-1)
+        n, H = idx.numel(), weight.size(1)
+        if n and (int(idx.min()) < 0 or int(idx.max()) >= weight.size(0)):
+            raise IndexError("embedding index out of range")
+        dev = weight.device
+        row_ptr = torch.arange(n + 1, dtype=torch.int32, device=dev)
+        idx32 = idx.to(torch.int32)
+        ones = torch.ones(n, dtype=torch.int32, device=dev)
+        out = torch.empty((n, H), dtype=torch.float32, device=dev)
+        nv.call("esc_bag_fwd", nv.ptr(weight), H, nv.ptr(row_ptr), nv.ptr(idx32), nv.ptr(ones), n, nv.ptr(out), H, nv.stream())
+        ctx.save_for_backward(idx)
+        ctx.rows, ctx.H = weight.size(0), H
+        return out.view(*index.shape, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g, ld = _rows(g.reshape(-1, ctx.H))
+        n, dev = idx.numel(), g.device
+        order = torch.sort(idx, stable=True)[1]
+        col_ptr = torch.zeros(ctx.rows + 1, dtype=torch.int32, device=dev)
+        col_ptr[1:] = torch.cumsum(torch.bincount(idx, minlength=ctx.rows), 0)
+        c_row = order.to(torch.int32)
+        c_val = torch.ones(n, dtype=torch.int32, device=dev)
+        c_col = idx[order].to(torch.int32)
+        dw = torch.empty((ctx.rows, ctx.H), dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(1, nv.lib().esc_bag_bwd_scratch(n, ctx.H)), dtype=torch.float32, device=dev)
+        nv.call("esc_bag_bwd_table", nv.ptr(g), ld, ctx.H, nv.ptr(col_ptr), nv.ptr(c_row), nv.ptr(c_val), nv.ptr(c_col),
+                n, ctx.rows, nv.ptr(dw), nv.ptr(scratch), nv.stream())
+        return dw, None
+
+
+def embedding(weight, index):
+    return _Embedding.apply(weight, index)

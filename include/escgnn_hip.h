@@ -118,6 +118,7 @@ int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t 
 
 /* ---- BatchNorm1d (training statistics) + ReLU, torch.nn.BatchNorm1d call sites
  * run_graphcount.py:55-60,66-72,80-87,115 --------------------------------------------------
+ * `relu` arguments below select the fused activation: 0 none, 1 ReLU, 2 ELU(alpha=1) (zinc_models.py:513-522).
  * stats: mean[C], invstd[C] of X[M,C] (biased variance, eps), optional running-stat update
  * (momentum, unbiased variance) exactly as torch does; then Y = relu?(gamma*(X-mean)*invstd+beta). */
 int64_t esc_bn_scratch(int64_t C);      /* floats of scratch the three calls below need */
@@ -181,6 +182,8 @@ typedef struct esc_batch_t {
   const int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
   const int32_t *row_ptr, *bag_idx, *bag_val, *col_ptr, *col_row, *col_val, *col_col;
 } esc_batch_t;
+/* run the x_embedding branch on a second HIP stream (event fork/join); default off */
+int esc_engine_set_side_stream(int on);
 int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z);
 /* loss[0] = sum|pred-y| / loss_denom (loss_denom <= 0: N).  pred (may be NULL): float[N]. */
 int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,

@@ -171,6 +171,25 @@ def main():
         np.savez_compressed(os.path.join(OUT, "collate_%s.npz" % tag), **store)
         print("wrote collate_%s.npz" % tag, sorted(b.keys))
 
+    # 8. ZINC-like batch: integer node types, integer edge types, graph-level y, no self loops (run_zinc.py:76)
+    rng = np.random.RandomState(9)
+    datas, store = [], {}
+    for j, seed in enumerate((21, 22, 23)):
+        n, s, t = gs.molecule_like_graph(seed)
+        d = ShimData(x=torch.tensor(rng.randint(0, 28, size=n)), edge_index=torch.tensor(np.stack([s, t])),
+                     edge_attr=torch.tensor(rng.randint(0, 4, size=s.shape[0])), y=torch.tensor([float(rng.randn())]))
+        o = ref_feat.create_subgraphs(d, 3, use_rd=True, self_loop=False)
+        datas.append(o)
+        for k in o.keys:
+            store["g%d_%s" % (j, k)] = o[k].numpy()
+    b = RefBatch.from_data_list(datas)
+    store["keys"] = np.array(sorted(b.keys))
+    for k in b.keys:
+        store["batch_" + k] = b[k].numpy()
+    store["num_graphs"] = np.int64(b.num_graphs)
+    np.savez_compressed(os.path.join(OUT, "collate_zinc3.npz"), **store)
+    print("wrote collate_zinc3.npz", sorted(b.keys))
+
     print("oracle disagreements:", bad, " elapsed %.1fs" % (time.time() - t0))
     if bad:
         raise SystemExit(1)

@@ -32,7 +32,7 @@ def reference_class(ref_file=REF_FILE):
     src = open(ref_file).read()
     tree = ast.parse(src)
     node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "NestedGIN_eff")
-    ns = dict(torch=torch, F=F, Linear=torch.nn.Linear, Sequential=torch.nn.Sequential, ReLU=torch.nn.ReLU,
+    ns = dict(torch=torch, F=F, ELU=torch.nn.ELU, Linear=torch.nn.Linear, Sequential=torch.nn.Sequential, ReLU=torch.nn.ReLU,
               BN=torch.nn.BatchNorm1d, Dropout=torch.nn.Dropout, GINEConv=rm.GINEConv,
               global_add_pool=rm.global_add_pool, global_mean_pool=rm.global_mean_pool)
     exec(compile(ast.Module(body=[node], type_ignores=[]), ref_file, "exec"), ns)
@@ -168,6 +168,55 @@ def main_sr():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; loss", float(res[0][1]))
 
 
+def main_zinc():
+    """zinc_models.py:504-611 (hidden is hard-wired to 256 there): 2 layers on the 3-graph ZINC-like batch."""
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "collate_zinc3.npz"))
+    b = {k[len("batch_"):]: torch.tensor(g[k]) for k in g.files if k.startswith("batch_")}
+    L = 2
+    torch.manual_seed(777)
+    Ref = reference_class("/root/reference/zinc_models.py")
+    ref = Ref(None, L)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if p.dim() == 1 and "bias" not in name:
+                p.add_(0.1 * torch.randn_like(p))
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    mine = rm.NestedGINEffZincRef(L)
+    assert list(mine.state_dict().keys()) == list(sd0.keys()), (list(mine.state_dict().keys())[:8], list(sd0.keys())[:8])
+    mine.load_state_dict(sd0)
+    res = []
+    for m, call in ((ref, lambda m: m(Bag(x=b["x"], edge_index=b["edge_index"], edge_attr=b["edge_attr"], batch=b["batch"],
+                                         pos_enc=b["pos_enc"], pos_index=b["pos_index"], pos_batch=b["pos_batch"]))),
+                    (mine, lambda m: m(b["x"], b["edge_index"], b["edge_attr"], b["pos_enc"], b["pos_index"],
+                                       b["pos_batch"], b["batch"]))):
+        m.train()
+        out = call(m)
+        loss = F.l1_loss(out, b["y"].view(-1, 1))
+        loss.backward()
+        res.append((out.detach(), loss.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    # parameters are 1.1 M floats at hidden=256: store the seed recipe instead of the tensors, plus outputs and a
+    # digest of every gradient (sum, abs-sum) for the comparison
+    out = {"keys": np.array(list(sd0.keys())), "pred": res[0][0].numpy(), "loss": res[0][1].numpy(), "layers": np.int64(L),
+           "seed": np.int64(777)}
+    for k, v in res[0][2].items():
+        out["gsum/" + k] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+    path = os.path.join(ROOT, "tests", "golden", "model_zinc.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; loss", float(res[0][1]))
+
+
+def zinc_reference_init(L=2, seed=777):
+    """Deterministic parameter recipe shared by the golden writer and the tests (torch CPU RNG)."""
+    torch.manual_seed(seed)
+    m = rm.NestedGINEffZincRef(L)
+    return m
+
+
 if __name__ == "__main__":
     main()
     main_sr()
+    main_zinc()

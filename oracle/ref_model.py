@@ -149,6 +149,45 @@ class NestedGINEffSRRef(torch.nn.Module):
         return o if self.use_cycle else F.log_softmax(o, dim=-1)
 
 
+class NestedGINEffZincRef(torch.nn.Module):
+    """zinc_models.py:504-611 composition: ELU, node/edge type embeddings, edge term [z_emb | edge_type_emb],
+    add-pool readout.  Same state_dict keys."""
+
+    def __init__(self, num_layers, hidden=256):
+        super().__init__()
+        from torch.nn import ELU
+
+        def mlp(i):
+            return Sequential(Linear(i, hidden), Dropout(0.0), BatchNorm1d(hidden), ELU(),
+                              Linear(hidden, hidden), Dropout(0.0), BatchNorm1d(hidden), ELU())
+        self.z_initial = torch.nn.Embedding(1800, hidden)
+        self.z_embedding = Sequential(Dropout(0.0), BatchNorm1d(hidden), ELU(), Linear(hidden, hidden), Dropout(0.0),
+                                      BatchNorm1d(hidden), ELU())
+        self.conv1 = GINEConv(mlp(32), train_eps=True, edge_dim=hidden + 32)
+        self.convs = torch.nn.ModuleList([GINEConv(mlp(hidden), train_eps=True, edge_dim=hidden + 32)
+                                          for _ in range(num_layers - 1)])
+        self.lin1 = Linear(num_layers * hidden, hidden)
+        self.bn_lin1 = BatchNorm1d(hidden, eps=1e-5, momentum=0.1)
+        self.lin2 = Linear(hidden, 1)
+        self.node_type_embedding = torch.nn.Embedding(100, 32)
+        self.edge_type_embedding = torch.nn.Embedding(100, 32)
+
+    def forward(self, x, edge_index, edge_attr, pos_enc, pos_index, pos_batch, batch):
+        h = self.node_type_embedding(x)
+        z = global_add_pool(self.z_initial.weight[pos_index] * pos_enc.view(-1, 1), pos_batch)
+        z = torch.cat((self.z_embedding(z), self.edge_type_embedding(edge_attr)), dim=-1)
+        h = self.conv1(h, edge_index, z)
+        xs = [h]
+        for conv in self.convs:
+            h = conv(h, edge_index, z)
+            xs.append(h)
+        o = global_add_pool(torch.cat(xs, dim=1), batch)
+        o = self.lin1(o)
+        if o.size(0) > 1:
+            o = self.bn_lin1(o)
+        return self.lin2(F.elu(o))
+
+
 def train_step(model, optimizer, b):
     """One optimisation step as run_graphcount.py:494-505 (L1 loss, mean over nodes)."""
     optimizer.zero_grad()

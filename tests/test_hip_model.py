@@ -206,3 +206,37 @@ def test_sr_variant_against_reference_golden():
     assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5
     for n, p in m.named_parameters():
         _close(p.grad, torch.tensor(z["grad/" + n]), "grad " + n, tol=1e-4)
+
+
+def test_zinc_variant_against_reference_golden():
+    """esc_gnn_amd.zinc_models.NestedGIN_eff (ELU-fused BatchNorm kernels, embeddings through the bag kernels,
+    [z_emb | edge_type] edge term, HIP add-pool) vs tests/golden/model_zinc.npz and an fp64 oracle."""
+    require_gpu()
+    import copy
+    import esc_gnn_amd as E
+    from esc_gnn_amd.zinc_models import NestedGIN_eff as ZincModel
+    from test_oracle_model import zinc_oracle_from_recipe
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(GOLDEN, "model_zinc.npz"))
+    ref = zinc_oracle_from_recipe(z)
+    m = ZincModel(None, int(z["layers"]))
+    assert list(m.state_dict().keys()) == [str(k) for k in z["keys"]]
+    m.load_state_dict(ref.state_dict())
+    m = m.to("cuda:0").train()
+    _, b, _ = load_collate("zinc3")
+    bt = {k: torch.tensor(v) for k, v in b.items()}
+    data = E.Data(**{k: v.clone() for k, v in bt.items()})
+    out = m(data)
+    loss = E.ops.l1_loss(out, bt["y"].float().to("cuda:0"))
+    loss.backward()
+    _close(out, torch.tensor(z["pred"]), "zinc predictions")
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5
+    ref.train()
+    ro = ref(bt["x"], bt["edge_index"], bt["edge_attr"], bt["pos_enc"], bt["pos_index"], bt["pos_batch"], bt["batch"])
+    torch.nn.functional.l1_loss(ro, bt["y"].view(-1, 1)).backward()
+    ref64 = copy.deepcopy(ref).double(); ref64.zero_grad()
+    r64 = ref64(bt["x"], bt["edge_index"], bt["edge_attr"], bt["pos_enc"], bt["pos_index"], bt["pos_batch"], bt["batch"])
+    torch.nn.functional.l1_loss(r64, bt["y"].double().view(-1, 1)).backward()
+    rp, rp64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for n, p in m.named_parameters():
+        _close_grad(n, p.grad, rp[n].grad, rp64[n].grad)

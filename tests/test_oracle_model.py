@@ -82,3 +82,33 @@ def test_sr_variant_matches_reference_composition():
     out = m(torch.tensor(z["x"]), b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
     loss = torch.nn.functional.nll_loss(out, torch.tensor(z["label"]))
     assert torch.equal(out.detach(), torch.tensor(z["logp"])) and torch.equal(loss.detach(), torch.tensor(z["loss"]))
+
+
+def zinc_oracle_from_recipe(z):
+    """Rebuild the parameters of tests/golden/model_zinc.npz from its seed recipe (the fixture keeps outputs and
+    gradient digests, not the 1.1 M parameters)."""
+    torch.manual_seed(int(z["seed"]))
+    m = rm.NestedGINEffZincRef(int(z["layers"]))
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() == 1 and "bias" not in name:
+                p.add_(0.1 * torch.randn_like(p))
+    return m
+
+
+def test_zinc_variant_matches_reference_composition():
+    """zinc_models.py:504-611 golden produced from the reference class body (ELU, type embeddings, add-pool)."""
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(GOLDEN, "model_zinc.npz"))
+    m = zinc_oracle_from_recipe(z)
+    assert list(m.state_dict().keys()) == [str(k) for k in z["keys"]]
+    _, b, _ = load_collate("zinc3")
+    b = {k: torch.tensor(v) for k, v in b.items()}
+    m.train()
+    out = m(b["x"], b["edge_index"], b["edge_attr"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
+    loss = torch.nn.functional.l1_loss(out, b["y"].view(-1, 1))
+    loss.backward()
+    assert torch.equal(out.detach(), torch.tensor(z["pred"])) and torch.equal(loss.detach(), torch.tensor(z["loss"]))
+    for n, p in m.named_parameters():
+        s = z["gsum/" + n]
+        assert abs(float(p.grad.double().sum()) - s[0]) <= 1e-6 * max(1.0, s[1]), n
