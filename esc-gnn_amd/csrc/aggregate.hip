@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
   const int lane = lane_id();
   const int beg = uniform(in_ptr[node]);
   const int end = uniform(in_ptr[node + 1]);
-  const float one_eps = __fadd_rn(1.0f, *eps_p);
+  const bool has_self = eps_p != nullptr;           // nullptr: plain neighbour sum (GINE+ per-distance terms)
+  const bool has_e = e != nullptr;                  // nullptr: message = relu(x_j)
+  const float one_eps = has_self ? __fadd_rn(1.0f, *eps_p) : 0.f;
   for (int c = lane * VEC; c < C; c += WAVE * VEC) {
     float acc[VEC], self[VEC];
 #pragma unroll
@@ -67,14 +69,14 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
         const int k = uniform(in_edge[jj]);
         const int s = uniform(in_src[jj]);
         const float* px = x + (size_t)s * ld_x + c;
-        const float* pe = e + (size_t)k * ld_e + c;
+        const float* pe = has_e ? e + (size_t)k * ld_e + c : px;
         if constexpr (VEC == 4) {
           const float4 a = *reinterpret_cast<const float4*>(px);
-          const float4 b = *reinterpret_cast<const float4*>(pe);
+          const float4 b = has_e ? *reinterpret_cast<const float4*>(pe) : make_float4(0.f, 0.f, 0.f, 0.f);
           xv[u][0] = a.x; xv[u][1] = a.y; xv[u][2] = a.z; xv[u][3] = a.w;
           ev[u][0] = b.x; ev[u][1] = b.y; ev[u][2] = b.z; ev[u][3] = b.w;
         } else {
-          xv[u][0] = *px; ev[u][0] = *pe;
+          xv[u][0] = *px; ev[u][0] = has_e ? *pe : 0.f;
         }
       }
 #pragma unroll
@@ -82,18 +84,17 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
         if (j + u < end) {                                  // wave-uniform: ascending-edge order is preserved
 #pragma unroll
           for (int t = 0; t < VEC; ++t)
-            acc[t] = __fadd_rn(acc[t], fmaxf(__fadd_rn(xv[u][t], ev[u][t]), 0.f));
+            acc[t] = __fadd_rn(acc[t], fmaxf(has_e ? __fadd_rn(xv[u][t], ev[u][t]) : xv[u][t], 0.f));
         }
       }
     }
     float* po = out + (size_t)node * ld_out + c;
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(po) =
-          make_float4(__fadd_rn(acc[0], __fmul_rn(one_eps, self[0])), __fadd_rn(acc[1], __fmul_rn(one_eps, self[1])),
-                      __fadd_rn(acc[2], __fmul_rn(one_eps, self[2])), __fadd_rn(acc[3], __fmul_rn(one_eps, self[3])));
-    } else {
-      *po = __fadd_rn(acc[0], __fmul_rn(one_eps, self[0]));
+    if (has_self) {
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[t] = __fadd_rn(acc[t], __fmul_rn(one_eps, self[t]));
     }
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else *po = acc[0];
   }
 }
 
@@ -108,13 +109,14 @@ __global__ __launch_bounds__(256) void agg_fwd_elem(const float* __restrict__ x,
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)N * C) return;
   const int node = (int)(t / C), c = (int)(t % C);
-  const float one_eps = __fadd_rn(1.0f, *eps_p);
   float acc = 0.f;
   for (int j = in_ptr[node]; j < in_ptr[node + 1]; ++j) {
-    const float v = __fadd_rn(x[(size_t)in_src[j] * ld_x + c], e[(size_t)in_edge[j] * ld_e + c]);
+    const float xs = x[(size_t)in_src[j] * ld_x + c];
+    const float v = e ? __fadd_rn(xs, e[(size_t)in_edge[j] * ld_e + c]) : xs;
     acc = __fadd_rn(acc, fmaxf(v, 0.f));
   }
-  out[(size_t)node * ld_out + c] = __fadd_rn(acc, __fmul_rn(one_eps, x[(size_t)node * ld_x + c]));
+  if (eps_p) acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(1.0f, *eps_p), x[(size_t)node * ld_x + c]));
+  out[(size_t)node * ld_out + c] = acc;
 }
 
 // ---- backward: one wave per SOURCE node (out-CSR) -------------------------------------------------
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
   const int lane = lane_id();
   const int beg = uniform(out_ptr[node]);
   const int end = uniform(out_ptr[node + 1]);
-  const float one_eps = 1.0f + *eps_p;
+  const bool has_self = eps_p != nullptr, has_e = e != nullptr;
+  const float one_eps = has_self ? 1.0f + *eps_p : 0.f;
   float dot = 0.f;
   for (int c = lane * VEC; c < C; c += WAVE * VEC) {
     float xi[VEC], gi[VEC], acc[VEC];
@@ -161,15 +164,15 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
         const int jj = min(j + u, end - 1);
         kk[u] = uniform(out_edge[jj]);
         const int d = uniform(out_dst[jj]);
-        const float* pe = e + (size_t)kk[u] * ld_e + c;
         const float* pg = g + (size_t)d * ld_g + c;
+        const float* pe = has_e ? e + (size_t)kk[u] * ld_e + c : pg;
         if constexpr (VEC == 4) {
-          const float4 a = *reinterpret_cast<const float4*>(pe);
+          const float4 a = has_e ? *reinterpret_cast<const float4*>(pe) : make_float4(0.f, 0.f, 0.f, 0.f);
           const float4 b = *reinterpret_cast<const float4*>(pg);
           ev[u][0] = a.x; ev[u][1] = a.y; ev[u][2] = a.z; ev[u][3] = a.w;
           gv[u][0] = b.x; gv[u][1] = b.y; gv[u][2] = b.z; gv[u][3] = b.w;
         } else {
-          ev[u][0] = *pe; gv[u][0] = *pg;
+          ev[u][0] = has_e ? *pe : 0.f; gv[u][0] = *pg;
         }
       }
 #pragma unroll
@@ -178,12 +181,14 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
           float o[VEC];
 #pragma unroll
           for (int t = 0; t < VEC; ++t) {
-            o[t] = (__fadd_rn(xi[t], ev[u][t]) > 0.f) ? gv[u][t] : 0.f;
+            o[t] = ((has_e ? __fadd_rn(xi[t], ev[u][t]) : xi[t]) > 0.f) ? gv[u][t] : 0.f;
             acc[t] += o[t];
           }
-          float* pd = d_e + (size_t)kk[u] * ld_de + c;
-          if constexpr (VEC == 4) *reinterpret_cast<float4*>(pd) = make_float4(o[0], o[1], o[2], o[3]);
-          else *pd = o[0];
+          if (d_e != nullptr) {
+            float* pd = d_e + (size_t)kk[u] * ld_de + c;
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(pd) = make_float4(o[0], o[1], o[2], o[3]);
+            else *pd = o[0];
+          }
         }
       }
     }
@@ -301,15 +306,15 @@ int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t
                            const int32_t* in_ptr, const int32_t* in_edge, const int32_t* in_src,
                            const float* eps, int64_t N, int64_t C, float* out, int64_t ld_out,
                            void* stream) {
-  ESC_REQUIRE(x && in_ptr && eps && out, "esc_gine_aggregate_fwd: null pointer");
-  ESC_REQUIRE(N >= 0 && C > 0 && ld_x >= C && ld_e >= C && ld_out >= C, "esc_gine_aggregate_fwd: bad sizes N=%ld C=%ld", (long)N, (long)C);
+  ESC_REQUIRE(x && in_ptr && out, "esc_gine_aggregate_fwd: null pointer");
+  ESC_REQUIRE(N >= 0 && C > 0 && ld_x >= C && (!e || ld_e >= C) && ld_out >= C, "esc_gine_aggregate_fwd: bad sizes N=%ld C=%ld", (long)N, (long)C);
   ESC_REQUIRE(N < (1LL << 31) / 64, "esc_gine_aggregate_fwd: N too large");
   if (N == 0) return ESC_OK;
-  ESC_REQUIRE(e && in_edge && in_src, "esc_gine_aggregate_fwd: null edge arrays");
+  ESC_REQUIRE(in_edge && in_src, "esc_gine_aggregate_fwd: null edge arrays");
   hipStream_t s = (hipStream_t)stream;
   if (C >= 64) {
-    const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_e % 4 == 0) && (ld_out % 4 == 0) &&
-                     esc::aligned16(x) && esc::aligned16(e) && esc::aligned16(out);
+    const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (!e || ld_e % 4 == 0) && (ld_out % 4 == 0) &&
+                     esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(out);
     const int64_t blocks = esc::cdiv(N, 4);
     if (vec)
       esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
@@ -328,16 +333,17 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                            const int32_t* out_edge, const int32_t* out_dst, const float* eps,
                            int64_t N, int64_t C, float* d_e, int64_t ld_de, float* dx,
                            int64_t ld_dx, int accumulate_dx, float* deps_part, void* stream) {
-  ESC_REQUIRE(x && g && out_ptr && eps, "esc_gine_aggregate_bwd: null pointer");
-  ESC_REQUIRE(N >= 0 && C > 0 && ld_x >= C && ld_e >= C && ld_g >= C && ld_de >= C && (!dx || ld_dx >= C),
+  ESC_REQUIRE(x && g && out_ptr, "esc_gine_aggregate_bwd: null pointer");
+  ESC_REQUIRE((e == nullptr) == (d_e == nullptr) || e != nullptr, "esc_gine_aggregate_bwd: d_e without e");
+  ESC_REQUIRE(N >= 0 && C > 0 && ld_x >= C && (!e || ld_e >= C) && ld_g >= C && (!d_e || ld_de >= C) && (!dx || ld_dx >= C),
               "esc_gine_aggregate_bwd: bad sizes");
   ESC_REQUIRE(N < (1LL << 31) / 64, "esc_gine_aggregate_bwd: N too large");
   if (N == 0) return ESC_OK;
-  ESC_REQUIRE(e && d_e && out_edge && out_dst, "esc_gine_aggregate_bwd: null edge arrays");
+  ESC_REQUIRE(out_edge && out_dst, "esc_gine_aggregate_bwd: null edge arrays");
   hipStream_t s = (hipStream_t)stream;
-  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_e % 4 == 0) && (ld_g % 4 == 0) && (ld_de % 4 == 0) &&
-                   (!dx || ld_dx % 4 == 0) && esc::aligned16(x) && esc::aligned16(e) && esc::aligned16(g) &&
-                   esc::aligned16(d_e) && (!dx || esc::aligned16(dx));
+  const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (!e || ld_e % 4 == 0) && (ld_g % 4 == 0) && (!d_e || ld_de % 4 == 0) &&
+                   (!dx || ld_dx % 4 == 0) && esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(g) &&
+                   (!d_e || esc::aligned16(d_e)) && (!dx || esc::aligned16(dx));
   const int64_t blocks = esc::cdiv(N, 4);
   if (vec)
     esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part);

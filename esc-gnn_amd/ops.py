@@ -313,3 +313,43 @@ class _Embedding(Function):
 
 def embedding(weight, index):
     return _Embedding.apply(weight, index)
+
+
+class _NeighbourSum(Function):
+    """out[i] = sum_{k: dst_k=i} relu(x[src_k] (+ e_k)) — GINE aggregate without the self term and with an
+    optional edge term: the per-distance message sum of GINEPLUS / NAIVEGINEPLUS
+    (modules/gine_operations.py:306-362)."""
+
+    @staticmethod
+    def forward(ctx, x, e, plan):
+        _dev(x, e)
+        x, ldx = _rows(x)
+        N, C = x.shape
+        lde = 0
+        if e is not None:
+            e, lde = _rows(e)
+            if e.shape != (plan.num_edges, C):
+                raise ValueError("neighbour_sum: edge term %s does not match %d edges x %d" % (tuple(e.shape), plan.num_edges, C))
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        nv.call("esc_gine_aggregate_fwd", nv.ptr(x), ldx, nv.ptr(e), lde, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge),
+                nv.ptr(plan.in_src), None, N, C, nv.ptr(out), C, nv.stream())
+        ctx.save_for_backward(x, e)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e = ctx.saved_tensors
+        plan = ctx.plan
+        g, ldg = _rows(g)
+        N, C = x.shape
+        d_e = torch.empty_like(e) if e is not None else None
+        dx = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        nv.call("esc_gine_aggregate_bwd", nv.ptr(x), x.stride(0), nv.ptr(e), e.stride(0) if e is not None else 0,
+                nv.ptr(g), ldg, nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), None, N, C,
+                nv.ptr(d_e), C if d_e is not None else 0, nv.ptr(dx), C, 0, None, nv.stream())
+        return dx, d_e, None
+
+
+def neighbour_sum(x, e, plan):
+    return _NeighbourSum.apply(x, e, plan)

@@ -55,7 +55,8 @@ int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* 
  * semantics GraphGPS/graphgps/layer/gine_conv_layer.py:56-84) -------------------------------
  * out[i,:] = (1+eps)*x[i,:] + sum_{k in in(i), ascending k} relu(x[src_k,:] + e[k,:]).
  * in_ptr/in_edge/in_src = CSR by destination from esc_csr_build(key=dst, other=src).
- * eps: device scalar.  Leading dimensions in floats. */
+ * eps: device scalar.  Leading dimensions in floats.  e == NULL: message = relu(x[src]); eps == NULL: no
+ * self term (plain neighbour sum) — the two forms GINEPLUS needs (modules/gine_operations.py:335-362). */
 int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t ld_e,
                            const int32_t* in_ptr, const int32_t* in_edge, const int32_t* in_src,
                            const float* eps, int64_t N, int64_t C, float* out, int64_t ld_out,
