@@ -197,7 +197,7 @@ def main():
         extra["roofline_mfma"] = dict(kernel="esc::gemm_tile_kernel (fp32 MFMA linears, fwd+dX+dW)", bound="mfma",
                                       achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                       frac=round(tf / MFMA_F32_PEAK_TF, 4), flops_per_step=int(fl))
-    cpu = cpu_baseline(args, graphs) if args.cpu_seconds > 0 else None
+    cpu = cpu_baseline(args, graphs) if (args.cpu_seconds > 0 and world == 1) else None   # rank 0, N=1 only
 
     out = {
         "metric": "graphs/sec + edges-aggregated/sec, NestedGIN_eff h=3 bs=128 @1/2/4/8 GPU",

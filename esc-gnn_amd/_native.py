@@ -56,6 +56,7 @@ SIGNATURES = {
     "esc_affine_act": [P, I64, I64, I64, P, P, I32, P, I64, P],
     "esc_bn_eval_coef": [P, P, P, P, F32, I64, P, P, P],
     "esc_engine_set_side_stream": [I32],
+    "esc_engine_set_materialise_edge_act": [I32],
     "esc_engine_workspace_floats": [P, I64, I64, I64],
     "esc_engine_train_step": [P, P, P, I64, P, P, P],
     "esc_engine_predict": [P, P, P, P, P],

@@ -33,6 +33,7 @@ struct Layout {
   int64_t N, E, Z, H, L, C0, W;   // W = (L+1)*H
   // forward state
   float *Zb, *Yz; BnWs zb0, zb1;
+  float *A0, *Zemb;               // relu(BN(Zb)) and z_emb = relu(BN(Yz)), materialised when g_materialise_edge_act
   float* e[ESC_MAX_LAYERS]; float* agg[ESC_MAX_LAYERS]; MlpWs conv[ESC_MAX_LAYERS];
   MlpWs xemb; float *cat, *Yl; BnWs bl; float *pred, *dpred;
   // backward scratch
@@ -51,6 +52,7 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   const int64_t H = m->hidden, L = m->num_layers, C0 = m->in_dim;
   y.N = N; y.E = E; y.Z = Z; y.H = H; y.L = L; y.C0 = C0; y.W = (L + 1) * H;
   y.Zb = a.take(E * H); y.Yz = a.take(E * H); y.zb0 = take_bn(a, H); y.zb1 = take_bn(a, H);
+  y.A0 = a.take(E * H); y.Zemb = a.take(E * H);
   for (int l = 0; l < L; ++l) {
     const int64_t C = l == 0 ? C0 : H;
     y.e[l] = a.take(E * C);
@@ -101,6 +103,9 @@ struct SideStream {
   hipEvent_t fork_f = nullptr, join_f = nullptr, fork_b = nullptr, join_b = nullptr;
   bool ok = false;
 };
+// Edge-sized activations: the affine+ReLU prologue costs the edge-row GEMMs ~25 % (VALU-bound staging), more
+// than the two extra elementwise passes that materialise them once; node-sized MLP activations stay fused.
+static int g_materialise_edge_act = 1;
 static int g_use_side_stream = 0;     // esc_engine_set_side_stream(); measured neutral-to-negative on MI355X r01
 
 static SideStream& side_stream() {
@@ -167,8 +172,15 @@ static int forward(const Ctx& c) {
   // ESC bag + z_embedding (reference :155-156)
   ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, c.s));
   ESC_TRY(bn_coeffs(c, y.Zb, H, E, m->zbn0, y.zb0));
-  ESC_TRY(esc_linear_fwd(y.Zb, H, m->zlin.w, H, m->zlin.b, y.zb0.scale, y.zb0.shift, E, H, H, y.Yz, H, nullptr, c.s));
-  ESC_TRY(bn_coeffs(c, y.Yz, H, E, m->zbn1, y.zb1));                      // z_emb = relu(Yz*scale+shift), virtual
+  const bool mat = g_materialise_edge_act != 0;
+  if (mat) {
+    ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, c.s));
+    ESC_TRY(esc_linear_fwd(y.A0, H, m->zlin.w, H, m->zlin.b, nullptr, nullptr, E, H, H, y.Yz, H, nullptr, c.s));
+  } else {
+    ESC_TRY(esc_linear_fwd(y.Zb, H, m->zlin.w, H, m->zlin.b, y.zb0.scale, y.zb0.shift, E, H, H, y.Yz, H, nullptr, c.s));
+  }
+  ESC_TRY(bn_coeffs(c, y.Yz, H, E, m->zbn1, y.zb1));                      // z_emb = relu(Yz*scale+shift)
+  if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, c.s));
   // xs[0] = x_embedding(x) (reference :166) — side stream
   SideStream& ss = side_stream();
   if (ss.ok) {
@@ -188,7 +200,8 @@ static int forward(const Ctx& c) {
     const int64_t C = l == 0 ? y.C0 : H;
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
-    ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], C, nullptr, c.s));
+    if (mat) ESC_TRY(esc_linear_fwd(y.Zemb, H, cv.lin.w, H, cv.lin.b, nullptr, nullptr, E, C, H, y.e[l], C, nullptr, c.s));
+    else     ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], C, nullptr, c.s));
     ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
     ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W));
   }
@@ -237,16 +250,25 @@ static int backward(const Ctx& c) {
     ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
                                    y.d_e, C, dx, W, 1, y.deps_part, c.s));
     ESC_TRY(esc_reduce_sum(y.deps_part, N, cv.deps, c.s));
-    ESC_TRY(esc_linear_bwd_both(y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin.w, H, E, C, H, y.dZemb, H,
-                                l == (int)L - 1 ? 0 : 1, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
+    if (g_materialise_edge_act)
+      ESC_TRY(esc_linear_bwd_both(y.d_e, C, y.Zemb, H, nullptr, nullptr, cv.lin.w, H, E, C, H, y.dZemb, H,
+                                  l == (int)L - 1 ? 0 : 1, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
+    else
+      ESC_TRY(esc_linear_bwd_both(y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin.w, H, E, C, H, y.dZemb, H,
+                                  l == (int)L - 1 ? 0 : 1, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
   }
   if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
   // z_embedding + bag
-  ESC_TRY(esc_bn_bwd(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma, m->zbn1.beta, 1,
-                     y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, y.bn_scratch, c.s));
-  ESC_TRY(esc_linear_bwd_both(y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin.w, H, E, H, H, y.dAz, H, 0, m->zlin.dw,
-                              H, m->zlin.db, y.slabs, c.s));
-  ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
+  const bool mat = g_materialise_edge_act != 0;
+  ESC_TRY(esc_bn_bwd(y.Yz, H, mat ? y.Zemb : nullptr, H, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma,
+                     m->zbn1.beta, 1, y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, y.bn_scratch, c.s));
+  if (mat)
+    ESC_TRY(esc_linear_bwd_both(y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin.w, H, E, H, H, y.dAz, H, 0, m->zlin.dw, H,
+                                m->zlin.db, y.slabs, c.s));
+  else
+    ESC_TRY(esc_linear_bwd_both(y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin.w, H, E, H, H, y.dAz, H, 0, m->zlin.dw,
+                                H, m->zlin.db, y.slabs, c.s));
+  ESC_TRY(esc_bn_bwd(y.Zb, H, mat ? y.A0 : nullptr, H, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, y.bn_scratch, c.s));
   ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
                             y.bag_scratch, c.s));
@@ -275,6 +297,11 @@ extern "C" {
 
 int esc_engine_set_side_stream(int on) {
   g_use_side_stream = on != 0;
+  return ESC_OK;
+}
+
+int esc_engine_set_materialise_edge_act(int on) {
+  g_materialise_edge_act = on != 0;
   return ESC_OK;
 }
 

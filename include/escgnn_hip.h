@@ -185,6 +185,9 @@ typedef struct esc_batch_t {
 } esc_batch_t;
 /* run the x_embedding branch on a second HIP stream (event fork/join); default off */
 int esc_engine_set_side_stream(int on);
+/* 1 (default): write relu(BN(.)) of the two EDGE-sized z_embedding activations once instead of re-applying the
+ * affine+ReLU prologue in every consumer GEMM; 0: fully fused (less memory, slower on MI355X r01). */
+int esc_engine_set_materialise_edge_act(int on);
 int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z);
 /* loss[0] = sum|pred-y| / loss_denom (loss_denom <= 0: N).  pred (may be NULL): float[N]. */
 int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
