@@ -29,29 +29,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KPAD = 4;
 
-template <int ROWS, int BK>
+template <int ROWS, int BK, int NTHR = 256>
 struct KContigTile {            // [ROWS][BK+KPAD]
   static constexpr int LD = BK + KPAD;
   static constexpr int FLOATS = ROWS * LD;
   static constexpr int QPR = BK / 4;                           // float4 per row
-  static constexpr int PER_THREAD = ROWS * QPR / 256;          // float4 per thread
+  static constexpr int PER_THREAD = ROWS * QPR / NTHR;         // float4 per thread
+  static_assert(ROWS * QPR % NTHR == 0 && NTHR % QPR == 0, "tile must split evenly over the workgroup");
 };
-template <int COLS, int BK>
+template <int COLS, int BK, int NTHR = 256>
 struct RedMajorTile {           // [BK][COLS+KPAD]
   static constexpr int LD = COLS + KPAD;
   static constexpr int FLOATS = BK * LD;
-  static constexpr int PER_THREAD = BK * (COLS / 4) / 256;
+  static constexpr int PER_THREAD = BK * (COLS / 4) / NTHR;
+  static_assert(BK * (COLS / 4) % NTHR == 0 && NTHR % (COLS / 4) == 0, "tile must split evenly over the workgroup");
 };
 
 // ---- global -> register staging ------------------------------------------------------------------
 // k-contiguous: rows r0.. of `src` (ld), reduction range [k0, k0+BK); element (r, k) valid iff
 // r < rows && k < kdim.  Optional per-k affine+relu (fused BatchNorm+ReLU of the producer).
-template <int ROWS, int BK, bool PRO>
+template <int ROWS, int BK, int NTHR, bool PRO>
 __device__ __forceinline__ bool load_kcontig(const float* __restrict__ src, int64_t ld, int r0, int rows,
                                              int k0, int kdim, bool vec_ok,
                                              const float* __restrict__ sc, const float* __restrict__ sh,
-                                             float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
-  using T = KContigTile<ROWS, BK>;
+                                             float4 (&reg)[KContigTile<ROWS, BK, NTHR>::PER_THREAD]) {
+  using T = KContigTile<ROWS, BK, NTHR>;
   const int tid = threadIdx.x;
   const int kq = tid % T::QPR;
   const int k = k0 + kq * 4;
@@ -64,7 +66,7 @@ __device__ __forceinline__ bool load_kcontig(const float* __restrict__ src, int6
     // right before the LDS store one K-step later.
 #pragma unroll
     for (int p = 0; p < T::PER_THREAD; ++p) {
-      const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
+      const int r = r0 + tid / T::QPR + p * (NTHR / T::QPR);
       const int rc = min(r, rows - 1);
       reg[p] = *reinterpret_cast<const float4*>(src + (size_t)rc * ld + k);
     }
@@ -72,7 +74,7 @@ __device__ __forceinline__ bool load_kcontig(const float* __restrict__ src, int6
   }
 #pragma unroll
   for (int p = 0; p < T::PER_THREAD; ++p) {
-    const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
+    const int r = r0 + tid / T::QPR + p * (NTHR / T::QPR);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < rows) {
       const float* q = src + (size_t)r * ld + k;
@@ -92,14 +94,14 @@ __device__ __forceinline__ bool load_kcontig(const float* __restrict__ src, int6
   return false;
 }
 // prologue + row mask of a RAW k-contiguous tile (see load_kcontig)
-template <int ROWS, int BK, bool PRO>
+template <int ROWS, int BK, int NTHR, bool PRO>
 __device__ __forceinline__ void finish_kcontig(int r0, int rows, float4 s4, float4 h4,
-                                               float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
-  using T = KContigTile<ROWS, BK>;
+                                               float4 (&reg)[KContigTile<ROWS, BK, NTHR>::PER_THREAD]) {
+  using T = KContigTile<ROWS, BK, NTHR>;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int p = 0; p < T::PER_THREAD; ++p) {
-    const int r = r0 + tid / T::QPR + p * (256 / T::QPR);
+    const int r = r0 + tid / T::QPR + p * (NTHR / T::QPR);
     float4 v = reg[p];
     if constexpr (PRO) {
       v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
@@ -109,30 +111,30 @@ __device__ __forceinline__ void finish_kcontig(int r0, int rows, float4 s4, floa
     reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   }
 }
-template <int ROWS, int BK>
-__device__ __forceinline__ void store_kcontig(float* __restrict__ lds, const float4 (&reg)[KContigTile<ROWS, BK>::PER_THREAD]) {
-  using T = KContigTile<ROWS, BK>;
+template <int ROWS, int BK, int NTHR>
+__device__ __forceinline__ void store_kcontig(float* __restrict__ lds, const float4 (&reg)[KContigTile<ROWS, BK, NTHR>::PER_THREAD]) {
+  using T = KContigTile<ROWS, BK, NTHR>;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int p = 0; p < T::PER_THREAD; ++p) {
-    const int r = tid / T::QPR + p * (256 / T::QPR);
+    const int r = tid / T::QPR + p * (NTHR / T::QPR);
     *reinterpret_cast<float4*>(lds + r * T::LD + (tid % T::QPR) * 4) = reg[p];
   }
 }
 
 // reduction-major: rows (reduction) [k0, k0+BK) of `src`, columns c0..c0+COLS; valid iff k < kdim && c < cols.
 // Optional per-COLUMN affine+relu (for act(X) in the weight gradient).
-template <int COLS, int BK, bool PRO>
+template <int COLS, int BK, int NTHR, bool PRO>
 __device__ __forceinline__ bool load_redmajor(const float* __restrict__ src, int64_t ld, int k0, int kdim,
                                               int c0, int cols, bool vec_ok,
                                               const float* __restrict__ sc, const float* __restrict__ sh,
-                                              float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
+                                              float4 (&reg)[RedMajorTile<COLS, BK, NTHR>::PER_THREAD]) {
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;  // float4 per row
   if (vec_ok && c0 + COLS <= cols) {   // block-uniform fast path: RAW unconditional loads, clamped reduction row
 #pragma unroll
-    for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
-      const int f = tid + p * 256;
+    for (int p = 0; p < RedMajorTile<COLS, BK, NTHR>::PER_THREAD; ++p) {
+      const int f = tid + p * NTHR;
       const int kk = f / QPR, cq = f % QPR;
       const int kc = min(k0 + kk, kdim - 1);
       reg[p] = *reinterpret_cast<const float4*>(src + (size_t)kc * ld + c0 + cq * 4);
@@ -140,8 +142,8 @@ __device__ __forceinline__ bool load_redmajor(const float* __restrict__ src, int
     return true;
   }
 #pragma unroll
-  for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
-    const int f = tid + p * 256;
+  for (int p = 0; p < RedMajorTile<COLS, BK, NTHR>::PER_THREAD; ++p) {
+    const int f = tid + p * NTHR;
     const int kk = f / QPR, cq = f % QPR;
     const int k = k0 + kk, c = c0 + cq * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -162,15 +164,15 @@ __device__ __forceinline__ bool load_redmajor(const float* __restrict__ src, int
   }
   return false;
 }
-template <int COLS, int BK, bool PRO>
+template <int COLS, int BK, int NTHR, bool PRO>
 __device__ __forceinline__ void finish_redmajor(int k0, int kdim, float4 s4, float4 h4,
-                                                float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
+                                                float4 (&reg)[RedMajorTile<COLS, BK, NTHR>::PER_THREAD]) {
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;
-  static_assert(256 % QPR == 0, "a thread keeps the same column quad for every pass");
+  static_assert(NTHR % QPR == 0, "a thread keeps the same column quad for every pass");
 #pragma unroll
-  for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
-    const int f = tid + p * 256;
+  for (int p = 0; p < RedMajorTile<COLS, BK, NTHR>::PER_THREAD; ++p) {
+    const int f = tid + p * NTHR;
     const int kk = f / QPR;
     float4 v = reg[p];
     if constexpr (PRO) {
@@ -181,14 +183,14 @@ __device__ __forceinline__ void finish_redmajor(int k0, int kdim, float4 s4, flo
     reg[p] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   }
 }
-template <int COLS, int BK>
-__device__ __forceinline__ void store_redmajor(float* __restrict__ lds, const float4 (&reg)[RedMajorTile<COLS, BK>::PER_THREAD]) {
+template <int COLS, int BK, int NTHR>
+__device__ __forceinline__ void store_redmajor(float* __restrict__ lds, const float4 (&reg)[RedMajorTile<COLS, BK, NTHR>::PER_THREAD]) {
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;
 #pragma unroll
-  for (int p = 0; p < RedMajorTile<COLS, BK>::PER_THREAD; ++p) {
-    const int f = tid + p * 256;
-    *reinterpret_cast<float4*>(lds + (f / QPR) * RedMajorTile<COLS, BK>::LD + (f % QPR) * 4) = reg[p];
+  for (int p = 0; p < RedMajorTile<COLS, BK, NTHR>::PER_THREAD; ++p) {
+    const int f = tid + p * NTHR;
+    *reinterpret_cast<float4*>(lds + (f / QPR) * RedMajorTile<COLS, BK, NTHR>::LD + (f % QPR) * 4) = reg[p];
   }
 }
 
@@ -227,14 +229,20 @@ struct GemmArgs {
   int a_vec, b_vec, c_slab; // alignment flags; c_slab: C is a [splits][rowsC][colsC] slab buffer
 };
 
-template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
+template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB, int KW = 1>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restrict__ lds, int bx, int by, int bz) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  // KW > 1: KW wave groups share ONE output tile and split every K-step between them (wave group wk owns
+  // 8-chunks [wk*BK/8/KW, (wk+1)*BK/8/KW)); their accumulators are summed through LDS in group order at
+  // the end.  Node-sized layers only have ~600 32x32 output blocks, i.e. 0.6 waves per SIMD — splitting K
+  // in the workgroup is what puts >2 waves on every SIMD so MFMA, LDS and barrier phases overlap.
+  constexpr int NTHR = WM * WN * KW * 64;
+  static_assert(!DB || KW == 1, "bias-gradient column sums assume one wave group");
+  static_assert((BK / 8) % KW == 0, "K-step must split evenly over the wave groups");
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NT = TN / 32;
   static_assert(MT >= 1 && NT >= 1, "wave tile must hold at least one 32x32 block");
-  using ATile = typename std::conditional<A_KC, KContigTile<BM, BK>, RedMajorTile<BM, BK>>::type;
-  using BTile = typename std::conditional<B_KC, KContigTile<BN, BK>, RedMajorTile<BN, BK>>::type;
+  using ATile = typename std::conditional<A_KC, KContigTile<BM, BK, NTHR>, RedMajorTile<BM, BK, NTHR>>::type;
+  using BTile = typename std::conditional<B_KC, KContigTile<BN, BK, NTHR>, RedMajorTile<BN, BK, NTHR>>::type;
   constexpr int STAGE = ATile::FLOATS + BTile::FLOATS;   // one K-step of A then B (LDS holds 2 stages)
 
   const int m0 = by * BM;
@@ -243,7 +251,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
   const int red0 = split * g.red_per_split;
   const int red1 = min(g.red, red0 + g.red_per_split);
   const int wave = threadIdx.x >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wk = wave / (WM * WN);
+  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
   const int l = lane_id();
 
   f32x16 acc[MT][NT];
@@ -286,25 +295,25 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
         ph = *reinterpret_cast<const float4*>(g.pro_shift + k);
       }
     }
-    if constexpr (A_KC) rawa = load_kcontig<BM, BK, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
-    else                rawa = load_redmajor<BM, BK, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
-    if constexpr (B_KC) rawb = load_kcontig<BN, BK, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
-    else                rawb = load_redmajor<BN, BK, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
+    if constexpr (A_KC) rawa = load_kcontig<BM, BK, NTHR, PRO>(g.A, g.lda, m0, g.rowsC, k0, red1, g.a_vec, g.pro_scale, g.pro_shift, ra);
+    else                rawa = load_redmajor<BM, BK, NTHR, false>(g.A, g.lda, k0, red1, m0, g.rowsC, g.a_vec, nullptr, nullptr, ra);
+    if constexpr (B_KC) rawb = load_kcontig<BN, BK, NTHR, false>(g.B, g.ldb, n0, g.colsC, k0, red1, g.b_vec, nullptr, nullptr, rb);
+    else                rawb = load_redmajor<BN, BK, NTHR, PRO && !A_KC>(g.B, g.ldb, k0, red1, n0, g.colsC, g.b_vec, g.pro_scale, g.pro_shift, rb);
     return (rawa ? 1 : 0) | (rawb ? 2 : 0);
   };
   auto lstore = [&](int buf, int k0, int raw, float4 (&ra)[ATile::PER_THREAD], float4 (&rb)[BTile::PER_THREAD], float4 ps, float4 ph) {
     if (raw & 1) {
-      if constexpr (A_KC) finish_kcontig<BM, BK, PRO>(m0, g.rowsC, ps, ph, ra);
-      else                finish_redmajor<BM, BK, false>(k0, red1, zero4, zero4, ra);
+      if constexpr (A_KC) finish_kcontig<BM, BK, NTHR, PRO>(m0, g.rowsC, ps, ph, ra);
+      else                finish_redmajor<BM, BK, NTHR, false>(k0, red1, zero4, zero4, ra);
     }
     if (raw & 2) {
-      if constexpr (B_KC) finish_kcontig<BN, BK, false>(n0, g.colsC, zero4, zero4, rb);
-      else                finish_redmajor<BN, BK, PRO && !A_KC>(k0, red1, pcs, pch, rb);
+      if constexpr (B_KC) finish_kcontig<BN, BK, NTHR, false>(n0, g.colsC, zero4, zero4, rb);
+      else                finish_redmajor<BN, BK, NTHR, PRO && !A_KC>(k0, red1, pcs, pch, rb);
     }
     float* a_w = lds + buf * STAGE;
     float* b_w = a_w + ATile::FLOATS;
-    if constexpr (A_KC) store_kcontig<BM, BK>(a_w, ra); else store_redmajor<BM, BK>(a_w, ra);
-    if constexpr (B_KC) store_kcontig<BN, BK>(b_w, rb); else store_redmajor<BN, BK>(b_w, rb);
+    if constexpr (A_KC) store_kcontig<BM, BK, NTHR>(a_w, ra); else store_redmajor<BM, BK, NTHR>(a_w, ra);
+    if constexpr (B_KC) store_kcontig<BN, BK, NTHR>(b_w, rb); else store_redmajor<BN, BK, NTHR>(b_w, rb);
   };
   auto compute = [&](int cur) {
     const float* a_l = lds + cur * STAGE;
@@ -316,7 +325,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
       }
     }
 #pragma unroll
-    for (int c8 = 0; c8 < BK / 8; ++c8) {
+    for (int cc = 0; cc < BK / 8 / KW; ++cc) {
+      const int c8 = wk * (BK / 8 / KW) + cc;
       float4 af[MT], bf[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -359,6 +369,29 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
     __syncthreads();
   }
 
+  if constexpr (KW > 1) {      // sum the KW partial accumulators in group order (deterministic) through LDS
+    constexpr int TILE_F = MT * NT * 16 * 64;                  // floats one wave holds
+    __syncthreads();                                           // staging buffers are dead from here on
+    float* red = lds + (size_t)(wave % (WM * WN)) * (KW - 1) * TILE_F;
+    if (wk > 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(size_t)(wk - 1) * TILE_F + ((i * NT + j) * 16 + r) * 64 + l] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int q = 0; q < KW - 1; ++q)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(size_t)q * TILE_F + ((i * NT + j) * 16 + r) * 64 + l];
+  }
   // ---- epilogue: C/D map of the 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Cbase = g.C + (g.c_slab ? (size_t)split * g.rowsC * g.ldc : 0);
 #pragma unroll
@@ -385,27 +418,27 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
+template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB, int KW = 1>
+__global__ __launch_bounds__(WM * WN * KW * 64) void gemm_tile_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  gemm_tile_body<BM, BN, WM, WN, BK, A_KC, B_KC, PRO, DB>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_tile_body<BM, BN, WM, WN, BK, A_KC, B_KC, PRO, DB, KW>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Backward of one Linear in ONE launch: the first gx workgroups compute dX = dY*W tiles, the rest the
 // split-M dW = dY^T*act(X) slabs.  Both stream the same dY; fusing them removes a launch boundary and lets
 // the two under-filled grids of the node-sized layers (152 + 304 workgroups) share the chip.
 struct DualArgs { GemmArgs dx; GemmArgs dw; int dx_nx, dx_ny, dw_nx, dw_ny, dw_nz; };
-template <int BM, int BN, int BK, bool PRO>
-__global__ __launch_bounds__(256) void gemm_bwd_dual_kernel(DualArgs a) {
+template <int BM, int BN, int WM, int WN, int BK, bool PRO>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bwd_dual_kernel(DualArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x;
   const int n_dx = a.dx_nx * a.dx_ny;
   if (b < n_dx) {
-    gemm_tile_body<BM, BN, 2, 2, BK, true, false, false, false>(a.dx, lds, b % a.dx_nx, b / a.dx_nx, 0);
+    gemm_tile_body<BM, BN, WM, WN, BK, true, false, false, false>(a.dx, lds, b % a.dx_nx, b / a.dx_nx, 0);
   } else {
     const int r = b - n_dx;
     const int per = a.dw_nx * a.dw_ny;
-    gemm_tile_body<BM, BN, 2, 2, BK, false, false, PRO, true>(a.dw, lds, (r % per) % a.dw_nx, (r % per) / a.dw_nx, r / per);
+    gemm_tile_body<BM, BN, WM, WN, BK, false, false, PRO, true>(a.dw, lds, (r % per) % a.dw_nx, (r % per) / a.dw_nx, r / per);
   }
 }
 
@@ -429,29 +462,40 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB>
+template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB, int KW = 1>
 static void launch_tile(const GemmArgs& g, int splits, hipStream_t s) {
-  using ATile = typename std::conditional<A_KC, KContigTile<BM, BK>, RedMajorTile<BM, BK>>::type;
-  using BTile = typename std::conditional<B_KC, KContigTile<BN, BK>, RedMajorTile<BN, BK>>::type;
-  constexpr size_t lds = 2 * (ATile::FLOATS + BTile::FLOATS) * sizeof(float);
+  constexpr int NTHR = WM * WN * KW * 64;
+  using ATile = typename std::conditional<A_KC, KContigTile<BM, BK, NTHR>, RedMajorTile<BM, BK, NTHR>>::type;
+  using BTile = typename std::conditional<B_KC, KContigTile<BN, BK, NTHR>, RedMajorTile<BN, BK, NTHR>>::type;
+  constexpr size_t lds_stage = 2 * (ATile::FLOATS + BTile::FLOATS) * sizeof(float);
+  constexpr size_t lds_red = (size_t)WM * WN * (KW - 1) * (BM / WM / 32) * (BN / WN / 32) * 16 * 64 * sizeof(float);
+  constexpr size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  auto kern = gemm_tile_kernel<BM, BN, WM, WN, BK, A_KC, B_KC, PRO, DB>;
+  auto kern = gemm_tile_kernel<BM, BN, WM, WN, BK, A_KC, B_KC, PRO, DB, KW>;
   if (lds > 64 * 1024) {
     static bool raised = false;          // per instantiation
     if (!raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
   }
   dim3 grid((unsigned)cdiv(g.colsC, BN), (unsigned)cdiv(g.rowsC, BM), (unsigned)splits);
-  esc::launch(ESC_K_LINEAR, kern, grid, dim3(256), lds, s, g);
+  esc::launch(ESC_K_LINEAR, kern, grid, dim3(NTHR), lds, s, g);
 }
 
 // tile shapes, selectable per call site (esc_tune_set) — ids are stable
 //   0: 128x128 BK32   1: 64x64 BK32   2: 128x32 BK32 (narrow outputs)   3: 128x64 BK32   4: 64x64 BK64
+//   5: 32x64 BK32, 2 waves   6: 32x32 BK32, 1 wave   7: 64x32 BK32, 2 waves   (smaller workgroups: measured slower)
+//   8: 32x32 tile, 4 wave groups splitting BK64   9: same with BK128   10: 64x32, 2 groups, BK64   (in-workgroup split-K)
 #define ESC_TILE_DISPATCH(ID, AKC, BKC, PRO, DB)                                                     \
   switch (ID) {                                                                                      \
     case 0: launch_tile<128, 128, 2, 2, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                 \
     case 2: launch_tile<128, 32, 4, 1, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                  \
     case 3: launch_tile<128, 64, 2, 2, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                  \
     case 4: launch_tile<64, 64, 2, 2, 64, AKC, BKC, PRO, DB>(g, splits, s); break;                   \
+    case 5: launch_tile<32, 64, 1, 2, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                   \
+    case 6: launch_tile<32, 32, 1, 1, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                   \
+    case 7: launch_tile<64, 32, 2, 1, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                   \
+    case 8: if constexpr (!(DB)) { launch_tile<32, 32, 1, 1, 64, AKC, BKC, PRO, false, 4>(g, splits, s); break; } \
+    case 9: if constexpr (!(DB)) { launch_tile<32, 32, 1, 1, 128, AKC, BKC, PRO, false, 4>(g, splits, s); break; } \
+    case 10: if constexpr (!(DB)) { launch_tile<64, 32, 2, 1, 64, AKC, BKC, PRO, false, 2>(g, splits, s); break; } \
     default: launch_tile<64, 64, 2, 2, 32, AKC, BKC, PRO, DB>(g, splits, s); break;                  \
   }
 
@@ -461,6 +505,9 @@ static void tile_dims(int id, int* bm, int* bn, int* bk) {
     case 2: *bm = 128; *bn = 32; *bk = 32; break;
     case 3: *bm = 128; *bn = 64; *bk = 32; break;
     case 4: *bm = 64; *bn = 64; *bk = 64; break;
+    case 5: *bm = 32; *bn = 64; *bk = 32; break;
+    case 6: *bm = 32; *bn = 32; *bk = 32; break;
+    case 7: *bm = 64; *bn = 32; *bk = 32; break;
     default: *bm = 64; *bn = 64; *bk = 32; break;
   }
 }
@@ -469,8 +516,8 @@ static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (l
 
 // tuning knobs (esc_tune_set): defaults chosen from scratch/gemm_bench.py sweeps on MI355X
 enum { KNOB_FWD_BIG = 0, KNOB_FWD_SMALL = 1, KNOB_DX_BIG = 2, KNOB_DX_SMALL = 3, KNOB_DW_TILE = 4,
-       KNOB_DW_BLOCKS = 5, KNOB_DW_MIN_ROWS = 6, KNOB_COUNT = 7 };
-static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128};
+       KNOB_DW_BLOCKS = 5, KNOB_DW_MIN_ROWS = 6, KNOB_DUAL_SMALL = 7, KNOB_COUNT = 8 };
+static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128, 0};
 
 }  // namespace esc
 
@@ -608,18 +655,19 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
 
 }  // extern "C"
 
-template <int BK, bool PRO>
+template <int BM, int BN, int WM, int WN, int BK, bool PRO>
 static void launch_dual(const DualArgs& a, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)(KContigTile<64, BK>::FLOATS + RedMajorTile<64, BK>::FLOATS) * sizeof(float);
-  constexpr size_t lds2 = 2 * (size_t)(2 * RedMajorTile<64, BK>::FLOATS) * sizeof(float);
+  constexpr int NTHR = WM * WN * 64;
+  constexpr size_t lds = 2 * (size_t)(KContigTile<BM, BK, NTHR>::FLOATS + RedMajorTile<BN, BK, NTHR>::FLOATS) * sizeof(float);
+  constexpr size_t lds2 = 2 * (size_t)(RedMajorTile<BM, BK, NTHR>::FLOATS + RedMajorTile<BN, BK, NTHR>::FLOATS) * sizeof(float);
   constexpr size_t need = lds > lds2 ? lds : lds2;
-  auto kern = gemm_bwd_dual_kernel<64, 64, BK, PRO>;
+  auto kern = gemm_bwd_dual_kernel<BM, BN, WM, WN, BK, PRO>;
   if (need > 64 * 1024) {
     static bool raised = false;
     if (!raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); raised = true; }
   }
   const unsigned blocks = (unsigned)(a.dx_nx * a.dx_ny + a.dw_nx * a.dw_ny * a.dw_nz);
-  esc::launch(ESC_K_LINEAR, kern, dim3(blocks), dim3(256), need, s, a);
+  esc::launch(ESC_K_LINEAR, kern, dim3(blocks), dim3(NTHR), need, s, a);
 }
 
 extern "C" {
@@ -638,9 +686,13 @@ int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t 
   ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_bwd_both: in_scale/in_shift must come together");
   ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_both: dimension too large");
   hipStream_t s = (hipStream_t)stream;
-  const int bk = M >= 8192 ? 32 : 64;
+  // edge-sized: 64x64xBK32 (4 workgroups/CU); node-sized: KNOB_DUAL_SMALL picks 64x64xBK64 (0) or the 2-wave
+  // 32x64xBK32 tile (1) that doubles the workgroup count of these under-filled grids
+  const int small_tile = g_knob[KNOB_DUAL_SMALL];
+  const int bm = (M >= 8192 || small_tile == 0) ? 64 : 32, bn = 64;
+  const int bk = (M >= 8192 || small_tile != 0) ? 32 : 64;
   int splits, per;
-  wgrad_plan_tile(M, N, K, 64, 64, bk, &splits, &per);
+  wgrad_plan_tile(M, N, K, bm, bn, bk, &splits, &per);
   DualArgs a{};
   GemmArgs& g = a.dx;
   g.A = dY; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.C = dX; g.ldc = ld_dx;
@@ -653,10 +705,11 @@ int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t 
   w.a_vec = vec_ok(dY, ld_dy);
   w.b_vec = vec_ok(X, ld_x) && (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
   w.c_slab = 1;
-  a.dx_nx = (int)cdiv(K, 64); a.dx_ny = (int)cdiv(M, 64);
-  a.dw_nx = (int)cdiv(K, 64); a.dw_ny = (int)cdiv(N, 64); a.dw_nz = splits;
-  if (bk == 32) { if (in_scale) launch_dual<32, true>(a, s); else launch_dual<32, false>(a, s); }
-  else          { if (in_scale) launch_dual<64, true>(a, s); else launch_dual<64, false>(a, s); }
+  a.dx_nx = (int)cdiv(K, bn); a.dx_ny = (int)cdiv(M, bm);
+  a.dw_nx = (int)cdiv(K, bn); a.dw_ny = (int)cdiv(N, bm); a.dw_nz = splits;
+  if (bm == 32)      { if (in_scale) launch_dual<32, 64, 1, 2, 32, true>(a, s); else launch_dual<32, 64, 1, 2, 32, false>(a, s); }
+  else if (bk == 32) { if (in_scale) launch_dual<64, 64, 2, 2, 32, true>(a, s); else launch_dual<64, 64, 2, 2, 32, false>(a, s); }
+  else               { if (in_scale) launch_dual<64, 64, 2, 2, 64, true>(a, s); else launch_dual<64, 64, 2, 2, 64, false>(a, s); }
   ESC_CHECK_LAUNCH("esc_linear_bwd_both.tiles");
   const int64_t n = N * K;
   esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,

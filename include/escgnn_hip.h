@@ -93,8 +93,9 @@ int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, c
                    float* Y, int64_t ld_y, float* col_stats, void* stream);
 /* tile-shape / split knobs of the three GEMM forms (benchmark sweeps; defaults are the tuned ones):
  * 0 fwd tile for M>=8192, 1 fwd tile for small M, 2/3 same for dX, 4 dW tile, 5 dW target workgroups,
- * 6 dW minimum reduction rows per split (>=128).
- * tile ids: 0 128x128xBK32, 1 64x64xBK32, 2 128x32xBK32, 3 128x64xBK32, 4 64x64xBK64. */
+ * 6 dW minimum reduction rows per split (>=128), 7 node-sized fused-backward tile (0: 64x64xBK64, 1: 32x64xBK32 2-wave).
+ * tile ids: 0 128x128xBK32, 1 64x64xBK32, 2 128x32xBK32, 3 128x64xBK32, 4 64x64xBK64, 5 32x64xBK32 (2 waves),
+ * 6 32x32xBK32 (1 wave), 7 64x32xBK32 (2 waves). */
 int esc_tune_set(int knob, int value);
 int esc_debug_gemm_occupancy(int tile_id);   /* resident workgroups/CU the runtime predicts (diagnostics) */
 /* dX[M,K] = dY[M,N] * W[N,K]  (accumulate!=0: dX += ...) */
