@@ -81,6 +81,28 @@ class DeviceGraphStore(object):
     def __len__(self):
         return self.num_graphs
 
+    # ---- on-disk cache: the processed dataset, like the reference's data_*.pt (GraphCountDataset.py:119-120) ----
+    _HOST = ("h_node_ptr", "h_edge_ptr", "h_nnz_ptr", "h_y_ptr")
+    _META = ("num_graphs", "x_dim", "y_dim", "y_is_vector")
+
+    def save(self, path):
+        """torch.save of every tensor of the store (sorted views included) — reload with DeviceGraphStore.load."""
+        blob = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.__dict__.items()
+                if torch.is_tensor(v) or k in self._META}
+        torch.save(blob, path)
+
+    @classmethod
+    def load(cls, path, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("DeviceGraphStore lives in HBM; there is no CPU fallback")
+        blob = torch.load(path, map_location="cpu", weights_only=True)
+        self = cls.__new__(cls)
+        self.device = dev
+        for k, v in blob.items():
+            setattr(self, k, v if (k in cls._HOST or k in cls._META) else v.to(dev))
+        return self
+
     def nbytes(self):
         return sum(v.numel() * v.element_size() for v in self.__dict__.values() if torch.is_tensor(v) and v.is_cuda)
 

@@ -67,3 +67,17 @@ def test_loader_and_model_on_collated_batch(E):
     out_dev = m(b)
     out_host = m(host)                 # foreign batch: plan derived on the fly
     assert torch.equal(out_dev, out_host)
+
+
+def test_store_cache_round_trip(E, tmp_path):
+    import os
+    store, datas, ref, _ = _store(E, "count3")
+    path = os.path.join(tmp_path, "data_tr.pt")
+    store.save(path)
+    again = E.DeviceGraphStore.load(path, "cuda:0")
+    a, b = store.collate([0, 1, 2]), again.collate([0, 1, 2])
+    for k in a.keys:
+        assert torch.equal(a[k], b[k]), k
+    pa, pb = a.__dict__["_esc_plan"], b.__dict__["_esc_plan"]
+    for f in E.BatchPlan.FIELDS:
+        assert torch.equal(getattr(pa, f), getattr(pb, f)), f
