@@ -112,7 +112,12 @@ class StepEngine(object):
         self._keep = [p for p in m.parameters()]
 
     def _batch(self, data, need_y):
+        dev = self.model.lin1.weight.device
+        if data.x.device != dev:
+            data.to(dev)
         plan = plan_of(data)
+        if plan.in_ptr.device != dev:
+            raise RuntimeError("StepEngine: batch plan lives on %s, model on %s" % (plan.in_ptr.device, dev))
         b = _Batch()
         b.N, b.E, b.Z = plan.num_nodes, plan.num_edges, plan.nnz
         x = data.x if data.x.is_contiguous() else data.x.contiguous()

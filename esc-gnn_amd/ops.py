@@ -19,6 +19,20 @@ def _dev(*tensors):
             raise TypeError("esc_gnn_amd: expected float32, got %s" % t.dtype)
 
 
+def _on(dev, *tensors):
+    """Every pointer handed to a kernel must be a DEVICE pointer on the same GPU: an index tensor left on the host
+    would be dereferenced by the GPU and fault.  Raise instead."""
+    for t in tensors:
+        if t is not None and t.device != dev:
+            raise RuntimeError("esc_gnn_amd: tensor on %s but the kernel runs on %s — move the batch to the device "
+                               "first (data.to(device))" % (t.device, dev))
+
+
+def _plan_on(dev, plan, *fields):
+    for f in fields:
+        _on(dev, getattr(plan, f))
+
+
 def _rows(t):
     """2-D, unit inner stride view + its leading dimension."""
     if t.dim() != 2:
@@ -38,6 +52,7 @@ class _Bag(Function):
         table = table.contiguous()
         if plan.row_ptr is None:
             raise ValueError("batch has no pos_enc/pos_index/pos_batch")
+        _plan_on(table.device, plan, "row_ptr", "bag_idx", "bag_val", "col_ptr", "col_row", "col_val", "col_col")
         E, H = plan.num_edges, table.size(1)
         out = torch.empty((E, H), dtype=torch.float32, device=table.device)
         nv.call("esc_bag_fwd", nv.ptr(table), H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx),
@@ -69,6 +84,8 @@ class _GineAggregate(Function):
     @staticmethod
     def forward(ctx, x, e, eps, plan):
         _dev(x, e, eps)
+        _on(x.device, e, eps)
+        _plan_on(x.device, plan, "in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst")
         x, ldx = _rows(x)
         e, lde = _rows(e)
         N, C = x.shape
@@ -112,6 +129,7 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         _dev(x, weight, bias)
+        _on(x.device, weight, bias)
         x, ldx = _rows(x)
         weight = weight.contiguous()
         M, K = x.shape
@@ -162,6 +180,7 @@ class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
         _dev(x, gamma, beta)
+        _on(x.device, gamma, beta, running_mean, running_var)
         x, ldx = _rows(x)
         M, C = x.shape
         if M <= 1:
@@ -201,6 +220,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, eps, momentum, rel
 def bn_eval_act(x, gamma, beta, running_mean, running_var, eps, relu):
     """Inference-mode BatchNorm (+ReLU) with running statistics — no autograd (eval/no_grad path)."""
     _dev(x)
+    _on(x.device, gamma, beta, running_mean, running_var)
     x, ldx = _rows(x)
     M, C = x.shape
     invstd = torch.rsqrt(running_var + eps)
@@ -217,6 +237,7 @@ class _L1Loss(Function):
     @staticmethod
     def forward(ctx, pred, y, denom):
         _dev(pred, y)
+        _on(pred.device, y)
         pred = pred.contiguous().view(-1)
         y = y.contiguous().view(-1)
         if pred.numel() != y.numel():
@@ -244,6 +265,7 @@ class _SegmentPool(Function):
     @staticmethod
     def forward(ctx, x, seg_ptr, mean):
         _dev(x)
+        _on(x.device, seg_ptr)
         x, ldx = _rows(x)
         G, C = seg_ptr.numel() - 1, x.size(1)
         out = torch.empty((G, C), dtype=torch.float32, device=x.device)
@@ -278,6 +300,7 @@ class _Embedding(Function):
     @staticmethod
     def forward(ctx, weight, index):
         _dev(weight)
+        _on(weight.device, index)
         weight = weight.contiguous()
         idx = index.reshape(-1)
         n, H = idx.numel(), weight.size(1)
@@ -323,6 +346,8 @@ class _NeighbourSum(Function):
     @staticmethod
     def forward(ctx, x, e, plan):
         _dev(x, e)
+        _on(x.device, e)
+        _plan_on(x.device, plan, "in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst")
         x, ldx = _rows(x)
         N, C = x.shape
         lde = 0
@@ -353,3 +378,34 @@ class _NeighbourSum(Function):
 
 def neighbour_sum(x, e, plan):
     return _NeighbourSum.apply(x, e, plan)
+
+
+class _SegmentBroadcast(Function):
+    """rows[batch] for a sorted batch vector (virtual-node embedding -> nodes, ogb_mol_gnn.py:744): the transpose of
+    global_add_pool, run by the segment-pool kernels."""
+
+    @staticmethod
+    def forward(ctx, rows, seg_ptr, n):
+        _dev(rows)
+        _on(rows.device, seg_ptr)
+        rows, ld = _rows(rows)
+        G, C = rows.shape
+        out = torch.empty((n, C), dtype=torch.float32, device=rows.device)
+        nv.call("esc_segment_pool_bwd", nv.ptr(rows), ld, nv.ptr(seg_ptr), G, C, 0, nv.ptr(out), C, nv.stream())
+        ctx.seg_ptr, ctx.G = seg_ptr, G
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g, ld = _rows(g)
+        C = g.size(1)
+        d = torch.empty((ctx.G, C), dtype=torch.float32, device=g.device)
+        nv.call("esc_segment_pool_fwd", nv.ptr(g), ld, nv.ptr(ctx.seg_ptr), ctx.G, C, 0, nv.ptr(d), C, nv.stream())
+        return d, None, None
+
+
+def segment_broadcast(rows, batch, size=None):
+    size = rows.size(0) if size is None else int(size)
+    seg_ptr = torch.zeros(size + 1, dtype=torch.int32, device=batch.device)
+    seg_ptr[1:] = torch.cumsum(torch.bincount(batch, minlength=size), 0)
+    return _SegmentBroadcast.apply(rows, seg_ptr, batch.numel())

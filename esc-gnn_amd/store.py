@@ -49,7 +49,11 @@ class DeviceGraphStore(object):
         self.node_ptr, self.edge_ptr = self.h_node_ptr.to(dev), self.h_edge_ptr.to(dev)
         self.nnz_ptr, self.y_ptr = self.h_nnz_ptr.to(dev), self.h_y_ptr.to(dev)
         self.num_graphs = G
+        self.x_is_int = not data_list[0].x.is_floating_point()       # categorical node features (ZINC / OGB)
+        self.x_was_1d = data_list[0].x.dim() == 1
         self.x_all = torch.cat([d.x.reshape(d.x.size(0), -1).float() for d in data_list]).contiguous().to(dev)
+        ea = [d.edge_attr for d in data_list]
+        self.edge_attr_all = None if any(a is None for a in ea) else torch.cat(ea, dim=0).contiguous().to(dev)
         self.y_all = torch.cat(ys).float().contiguous().to(dev)
         self.x_dim, self.y_dim = self.x_all.size(1), self.y_all.size(1)
         self.y_is_vector = all(d.y.dim() <= 1 for d in data_list)
@@ -83,7 +87,7 @@ class DeviceGraphStore(object):
 
     # ---- on-disk cache: the processed dataset, like the reference's data_*.pt (GraphCountDataset.py:119-120) ----
     _HOST = ("h_node_ptr", "h_edge_ptr", "h_nnz_ptr", "h_y_ptr")
-    _META = ("num_graphs", "x_dim", "y_dim", "y_is_vector")
+    _META = ("num_graphs", "x_dim", "y_dim", "y_is_vector", "x_is_int", "x_was_1d")
 
     def save(self, path):
         """torch.save of every tensor of the store (sorted views included) — reload with DeviceGraphStore.load."""
@@ -99,6 +103,7 @@ class DeviceGraphStore(object):
         blob = torch.load(path, map_location="cpu", weights_only=True)
         self = cls.__new__(cls)
         self.device = dev
+        self.edge_attr_all = None                             # optional tensors are absent from the blob when None
         for k, v in blob.items():
             setattr(self, k, v if (k in cls._HOST or k in cls._META) else v.to(dev))
         return self
@@ -163,7 +168,14 @@ class DeviceGraphStore(object):
             setattr(a, name, t.data_ptr())
         nv.call("esc_collate_fill", ctypes.byref(a), s)
         out = Batch()
+        if self.x_is_int:                                    # small categorical ids survive the fp32 round trip exactly
+            x = x.long().view(-1) if self.x_was_1d else x.long()
         out.x, out.edge_index = x, edge_index
+        if self.edge_attr_all is not None:                   # per-edge attributes: gather by a device-built index
+            cnt = (offs_d[1, 1:] - offs_d[1, :-1])
+            src0 = self.edge_ptr[ids_d]
+            gather = torch.arange(E, device=dev) + torch.repeat_interleave(src0 - offs_d[1, :-1], cnt)
+            out.edge_attr = self.edge_attr_all[gather]
         out.y = y.view(-1) if (self.y_is_vector and self.y_dim == 1) else y
         out.pos_enc, out.pos_index, out.pos_batch, out.batch = pos_enc, pos_index, pos_batch, batch
         plan = BatchPlan(in_ptr=in_ptr, in_edge=in_edge, in_src=in_src, out_ptr=out_ptr, out_edge=out_edge,

@@ -48,6 +48,9 @@ class Bag(object):
     def to(self, device):
         return self
 
+    def __contains__(self, key):
+        return key in self.__dict__
+
 
 def main():
     torch.set_num_threads(1)  # CPU index/scatter backward is run-to-run nondeterministic when threaded
@@ -216,7 +219,65 @@ def zinc_reference_init(L=2, seed=777):
     return m
 
 
+def reference_ogb_classes():
+    """exec AtomEncoder, GINConv_eff, GNN_node_efficient and GNN of /root/reference/ogb_mol_gnn.py on shim primitives."""
+    path = "/root/reference/ogb_mol_gnn.py"
+    tree = ast.parse(open(path).read())
+    want = ("AtomEncoder", "GINConv_eff", "GNN_node_efficient", "GNN")
+    nodes = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in want]
+    ns = dict(torch=torch, F=F, Linear=torch.nn.Linear, Sequential=torch.nn.Sequential, ReLU=torch.nn.ReLU,
+              Dropout=torch.nn.Dropout, MessagePassing=rm.MessagePassing, BondEncoder=rm.BondEncoder,
+              get_atom_feature_dims=lambda: list(rm.ATOM_FEATURE_DIMS), global_add_pool=rm.global_add_pool,
+              global_mean_pool=rm.global_mean_pool, GNN_node=None)
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), path, "exec"), ns)
+    return ns["GNN"]
+
+
+def main_ogb():
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "collate_molhiv4.npz"))
+    b = {k[len("batch_"):]: torch.tensor(g[k]) for k in g.files if k.startswith("batch_")}
+    L, H = 3, 32
+    torch.manual_seed(2024)
+    Ref = reference_ogb_classes()
+    ref = Ref("ogbg-molhiv", 1, num_layer=L, emb_dim=H, gnn_type="gin_eff", virtual_node=True, residual=True,
+              drop_ratio=0.0, JK="last", graph_pooling="mean")
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if p.dim() == 1 and "bias" not in name:
+                p.add_(0.1 * torch.randn_like(p))
+        ref.gnn_node.virtualnode_embedding.weight.add_(0.1 * torch.randn(1, H))
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    mine = rm.GNNEffRef(1, L, H, virtual_node=True, residual=True, drop_ratio=0.0, JK="last", graph_pooling="mean")
+    assert list(mine.state_dict().keys()) == list(sd0.keys()), [a for a, c in zip(mine.state_dict().keys(), sd0.keys()) if a != c][:5]
+    mine.load_state_dict(sd0)
+    y = b["y"].float().view(-1, 1)
+    res = []
+    for m, call in ((ref, lambda m: m(Bag(x=b["x"], edge_index=b["edge_index"], edge_attr=b["edge_attr"], batch=b["batch"],
+                                         pos_enc=b["pos_enc"], pos_index=b["pos_index"], pos_batch=b["pos_batch"]))),
+                    (mine, lambda m: m(b["x"], b["edge_index"], b["edge_attr"], b["batch"], b["pos_enc"], b["pos_index"],
+                                       b["pos_batch"]))):
+        m.train()
+        out = call(m)
+        loss = F.binary_cross_entropy_with_logits(out, y)         # run_ogb_mol.py:65-72 (cls criterion)
+        loss.backward()
+        res.append((out.detach(), loss.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    out = {"keys": np.array(list(sd0.keys())), "logit": res[0][0].numpy(), "loss": res[0][1].numpy(), "layers": np.int64(L),
+           "hidden": np.int64(H)}
+    for k, v in sd0.items():
+        out["param/" + k] = v.numpy()
+    for k, v in res[0][2].items():
+        out["grad/" + k] = v.numpy()
+    path = os.path.join(ROOT, "tests", "golden", "model_ogb.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; loss", float(res[0][1]))
+
+
 if __name__ == "__main__":
     main()
     main_sr()
     main_zinc()
+    main_ogb()

@@ -188,6 +188,142 @@ class NestedGINEffZincRef(torch.nn.Module):
         return self.lin2(F.elu(o))
 
 
+# ---- OGB gin_eff route (ogb_mol_gnn.py:264-282, 323-358, 614-792, 66-261) -------------------------------------
+ATOM_FEATURE_DIMS = (119, 5, 12, 12, 10, 6, 6, 2, 2)   # ogb==1.3.3 get_atom_feature_dims(), recalled (un-vendored)
+BOND_FEATURE_DIMS = (5, 6, 2)                          # ogb==1.3.3 get_bond_feature_dims()
+
+
+class MessagePassing(torch.nn.Module):
+    """PyG MessagePassing(aggr='add') reduced to what GINConv_eff uses: x_j = x[edge_index[0]], message(),
+    scatter-add at edge_index[1], update()."""
+
+    def __init__(self, aggr="add"):
+        super().__init__()
+        assert aggr == "add"
+
+    def propagate(self, edge_index, x, edge_attr):
+        msg = self.message(x_j=x.index_select(0, edge_index[0]), edge_attr=edge_attr)
+        return self.update(torch.zeros_like(x).index_add_(0, edge_index[1], msg))
+
+
+class BondEncoder(torch.nn.Module):
+    """ogb.graphproppred.mol_encoder.BondEncoder restated (sum of xavier-initialised embeddings)."""
+
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.bond_embedding_list = torch.nn.ModuleList()
+        for d in BOND_FEATURE_DIMS:
+            emb = torch.nn.Embedding(d, emb_dim)
+            torch.nn.init.xavier_uniform_(emb.weight.data)
+            self.bond_embedding_list.append(emb)
+
+    def forward(self, edge_attr):
+        out = 0
+        for i in range(edge_attr.shape[1]):
+            out = out + self.bond_embedding_list[i](edge_attr[:, i])
+        return out
+
+
+class AtomEncoderRef(torch.nn.Module):
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.atom_embedding_list = torch.nn.ModuleList()
+        for d in ATOM_FEATURE_DIMS:
+            emb = torch.nn.Embedding(d, emb_dim)
+            torch.nn.init.xavier_uniform_(emb.weight.data)
+            self.atom_embedding_list.append(emb)
+
+    def forward(self, x):
+        out = 0
+        for i in range(x.shape[1]):
+            out = out + self.atom_embedding_list[i](x[:, i])
+        return out
+
+
+class GINConvEffRef(MessagePassing):
+    def __init__(self, emb_dim):
+        super().__init__("add")
+        self.mlp = Sequential(Linear(emb_dim, 2 * emb_dim), BatchNorm1d(2 * emb_dim), ReLU(), Linear(2 * emb_dim, emb_dim))
+        self.eps = torch.nn.Parameter(torch.Tensor([0]))
+        self.edge_encoder = BondEncoder(emb_dim)
+        self.edge_encoder_pos = Linear(emb_dim, emb_dim)
+
+    def forward(self, x, edge_index, edge_attr, edge_pos):
+        e = self.edge_encoder(edge_attr) + self.edge_encoder_pos(edge_pos)
+        return self.mlp((1 + self.eps) * x + self.propagate(edge_index, x=x, edge_attr=e))
+
+    def message(self, x_j, edge_attr):
+        return F.relu(x_j + edge_attr)
+
+    def update(self, aggr_out):
+        return aggr_out
+
+
+class GNNEffRef(torch.nn.Module):
+    """GNN(gnn_type='gin_eff') with sum/mean pooling: same state_dict keys as the reference wrapper."""
+
+    class Node(torch.nn.Module):
+        def __init__(self, num_layer, emb_dim, drop_ratio, JK, residual, virtual_node):
+            super().__init__()
+            self.num_layer, self.drop_ratio, self.JK, self.residual, self.virtual_node = num_layer, drop_ratio, JK, residual, virtual_node
+            self.z_initial = torch.nn.Embedding(1800, emb_dim)
+            self.z_embedding = Sequential(Dropout(drop_ratio), BatchNorm1d(emb_dim), ReLU(), Linear(emb_dim, emb_dim),
+                                          Dropout(drop_ratio), BatchNorm1d(emb_dim), ReLU())
+            self.node_encoder = AtomEncoderRef(emb_dim)
+            if virtual_node:
+                self.virtualnode_embedding = torch.nn.Embedding(1, emb_dim)
+                torch.nn.init.constant_(self.virtualnode_embedding.weight.data, 0)
+            self.convs = torch.nn.ModuleList()
+            self.batch_norms = torch.nn.ModuleList()
+            for _ in range(num_layer):
+                self.convs.append(GINConvEffRef(emb_dim))
+                self.batch_norms.append(BatchNorm1d(emb_dim))
+            if virtual_node:
+                self.mlp_virtualnode_list = torch.nn.ModuleList()
+                for _ in range(num_layer - 1):
+                    self.mlp_virtualnode_list.append(Sequential(
+                        Linear(emb_dim, 2 * emb_dim), BatchNorm1d(2 * emb_dim), ReLU(),
+                        Linear(2 * emb_dim, emb_dim), BatchNorm1d(emb_dim), ReLU()))
+
+        def forward(self, x, edge_index, edge_attr, batch, pos_enc, pos_index, pos_batch):
+            B = int(batch[-1]) + 1
+            vn = self.virtualnode_embedding(torch.zeros(B, dtype=torch.long)) if self.virtual_node else None
+            h_list = [self.node_encoder(x)]
+            z = self.z_embedding(global_add_pool(self.z_initial.weight[pos_index] * pos_enc.view(-1, 1), pos_batch))
+            for layer in range(self.num_layer):
+                if self.virtual_node:
+                    h_list[layer] = h_list[layer] + vn[batch]
+                h = self.batch_norms[layer](self.convs[layer](h_list[layer], edge_index, edge_attr, z))
+                if layer == self.num_layer - 1:
+                    h = F.dropout(h, self.drop_ratio, training=self.training)
+                else:
+                    h = F.dropout(F.relu(h), self.drop_ratio, training=self.training)
+                if self.residual:
+                    h = h + h_list[layer]
+                h_list.append(h)
+                if self.virtual_node and layer < self.num_layer - 1:
+                    tmp = global_add_pool(h_list[layer], batch, B) + vn
+                    upd = F.dropout(self.mlp_virtualnode_list[layer](tmp), self.drop_ratio, training=self.training)
+                    vn = vn + upd if self.residual else upd
+            if self.JK == "last":
+                return h_list[-1]
+            out = 0
+            for layer in range(self.num_layer):
+                out = out + h_list[layer]
+            return out
+
+    def __init__(self, num_tasks, num_layer, emb_dim, virtual_node=True, residual=False, drop_ratio=0.0, JK="last",
+                 graph_pooling="mean"):
+        super().__init__()
+        self.gnn_node = GNNEffRef.Node(num_layer, emb_dim, drop_ratio, JK, residual, virtual_node)
+        self.pool = global_add_pool if graph_pooling == "sum" else global_mean_pool
+        self.graph_pred_linear = Linear(emb_dim, num_tasks)
+
+    def forward(self, x, edge_index, edge_attr, batch, pos_enc, pos_index, pos_batch):
+        h = self.gnn_node(x, edge_index, edge_attr, batch, pos_enc, pos_index, pos_batch)
+        return self.graph_pred_linear(self.pool(h, batch))
+
+
 def train_step(model, optimizer, b):
     """One optimisation step as run_graphcount.py:494-505 (L1 loss, mean over nodes)."""
     optimizer.zero_grad()

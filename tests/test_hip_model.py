@@ -240,3 +240,46 @@ def test_zinc_variant_against_reference_golden():
     rp, rp64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
     for n, p in m.named_parameters():
         _close_grad(n, p.grad, rp[n].grad, rp64[n].grad)
+
+
+def test_ogb_variant_against_reference_golden():
+    """esc_gnn_amd.ogb_mol_gnn.GNN(gnn_type='gin_eff') vs tests/golden/model_ogb.npz (reference class bodies on the
+    oracle primitives): logits, BCE loss, every gradient (fp64-oracle criterion)."""
+    require_gpu()
+    import copy
+    import esc_gnn_amd as E
+    from esc_gnn_amd.ogb_mol_gnn import GNN
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(GOLDEN, "model_ogb.npz"))
+    L, H = int(z["layers"]), int(z["hidden"])
+    keys = [str(k) for k in z["keys"]]
+    sd = {k: torch.tensor(z["param/" + k]) for k in keys}
+    m = GNN("ogbg-molhiv", 1, num_layer=L, emb_dim=H, gnn_type="gin_eff", virtual_node=True, residual=True,
+            drop_ratio=0.0, JK="last", graph_pooling="mean")
+    assert list(m.state_dict().keys()) == keys
+    m.load_state_dict(sd)
+    m = m.to("cuda:0").train()
+    _, b, _ = load_collate("molhiv4")
+    bt = {k: torch.tensor(v) for k, v in b.items()}
+    out = m(E.Data(**{k: v.clone() for k, v in bt.items()}))      # host batch: the model moves it (run_ogb_mol.py:58)
+    y = bt["y"].float().view(-1, 1)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, y.to("cuda:0"))
+    loss.backward()
+    _close(out, torch.tensor(z["logit"]), "ogb logits")
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-5
+    ref = rm.GNNEffRef(1, L, H, virtual_node=True, residual=True, drop_ratio=0.0)
+    ref.load_state_dict(sd)
+    ref64 = copy.deepcopy(ref).double().train()
+    o64 = ref64(bt["x"], bt["edge_index"], bt["edge_attr"], bt["batch"], bt["pos_enc"], bt["pos_index"], bt["pos_batch"])
+    torch.nn.functional.binary_cross_entropy_with_logits(o64, y.double()).backward()
+    rp64 = dict(ref64.named_parameters())
+    for n, p in m.named_parameters():
+        _close_grad(n, p.grad, torch.tensor(z["grad/" + n]), rp64[n].grad)
+    # eval mode (running statistics) and the collate of the molhiv-like graphs through the device store
+    m.eval()
+    graphs, _, _ = load_collate("molhiv4")
+    store = E.DeviceGraphStore([E.Data(**{k: torch.tensor(v) for k, v in g.items()}) for g in graphs], "cuda:0")
+    with torch.no_grad():
+        a = m(store.collate([0, 1, 2, 3]))
+        c = m(E.Data(**{k: v.clone() for k, v in bt.items()}))
+    assert torch.equal(a, c)

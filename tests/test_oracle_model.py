@@ -112,3 +112,20 @@ def test_zinc_variant_matches_reference_composition():
     for n, p in m.named_parameters():
         s = z["gsum/" + n]
         assert abs(float(p.grad.double().sum()) - s[0]) <= 1e-6 * max(1.0, s[1]), n
+
+
+def test_ogb_variant_matches_reference_composition():
+    """ogb_mol_gnn.py gin_eff route (GNN / GNN_node_efficient / GINConv_eff / AtomEncoder class bodies exec'd on the
+    oracle primitives) -> tests/golden/model_ogb.npz."""
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(GOLDEN, "model_ogb.npz"))
+    m = rm.GNNEffRef(1, int(z["layers"]), int(z["hidden"]), virtual_node=True, residual=True, drop_ratio=0.0)
+    keys = [str(k) for k in z["keys"]]
+    assert list(m.state_dict().keys()) == keys
+    m.load_state_dict({k: torch.tensor(z["param/" + k]) for k in keys})
+    _, b, _ = load_collate("molhiv4")
+    b = {k: torch.tensor(v) for k, v in b.items()}
+    m.train()
+    out = m(b["x"], b["edge_index"], b["edge_attr"], b["batch"], b["pos_enc"], b["pos_index"], b["pos_batch"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, b["y"].float().view(-1, 1))
+    assert torch.equal(out.detach(), torch.tensor(z["logit"])) and torch.equal(loss.detach(), torch.tensor(z["loss"]))
