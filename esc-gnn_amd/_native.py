@@ -49,6 +49,8 @@ SIGNATURES = {
     "esc_linear_bwd_weight_scratch": [I64, I64, I64],
     "esc_linear_bwd_weight": [P, I64, P, I64, P, P, I64, I64, I64, P, I64, P, P, P],
     "esc_linear_bwd_both": [P, I64, P, I64, P, P, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, P, P],
+    "esc_linear_bwd_both_deferred": [P, I64, P, I64, P, P, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, P, P, P],
+    "esc_slab_reduce_jobs": [P, I32, P],
     "esc_bn_scratch": [I64],
     "esc_bn_stats": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P, P],
     "esc_bn_apply": [P, I64, I64, I64, P, P, P, P, I32, P, I64, P],

@@ -14,6 +14,8 @@
 // use_cycle=True — the configuration run_graphcount.py:465 instantiates).
 #include "common.h"
 
+#include <vector>
+
 namespace esc {
 
 struct Arena {
@@ -72,9 +74,15 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
     y.dagg = a.take(N * H); y.d_e = a.take(E * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
     y.deps_part = a.take(N);
     y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
-    int64_t sl = esc_linear_bwd_weight_scratch(E, H, H);
-    const int64_t s2 = esc_linear_bwd_weight_scratch(N, H, y.W);
-    if (s2 > sl) sl = s2;
+    // one private slab region per weight gradient: their ordered reduces are deferred to ONE launch at the end
+    int64_t sl = esc_linear_bwd_weight_scratch(E, H, H) + 64;                        // zlin
+    for (int l = 0; l < L; ++l) {
+      const int64_t C = l == 0 ? C0 : H;
+      sl += esc_linear_bwd_weight_scratch(E, C, H) + esc_linear_bwd_weight_scratch(N, H, H) +
+            esc_linear_bwd_weight_scratch(N, H, C) + 3 * 64;                           // conv.lin, nn.lin1, nn.lin0
+    }
+    sl += esc_linear_bwd_weight_scratch(N, H, H) + esc_linear_bwd_weight_scratch(N, H, C0) + 2 * 64;   // x_embedding
+    sl += esc_linear_bwd_weight_scratch(N, H, y.W) + esc_linear_bwd_weight_scratch(N, 1, H) + 2 * 64;  // lin1, lin2
     y.slabs = a.take(sl);
   }
   y.total = a.off;
@@ -93,7 +101,23 @@ struct Ctx {
   Layout y;
   void* s;
   bool train;
+  std::vector<esc_reduce_job>* jobs = nullptr;   // deferred weight-gradient reduces (main chain only)
+  float** slab_cursor = nullptr;
 };
+
+// dX + dW tiles now, slab reduce deferred (or immediate when the context has no job list)
+static int linear_backward(const Ctx& c, const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* sc,
+                           const float* sh, const esc_linear_t& lin, int64_t M, float* dX, int64_t ld_dx, int accumulate) {
+  const int64_t N = lin.out_dim, K = lin.in_dim;
+  if (c.jobs == nullptr)
+    return esc_linear_bwd_both(dY, ld_dy, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db,
+                               c.y.slabs, c.s);
+  float* slabs = *c.slab_cursor;
+  *c.slab_cursor += (esc_linear_bwd_weight_scratch(M, N, K) + 63) & ~63LL;
+  c.jobs->emplace_back();
+  return esc_linear_bwd_both_deferred(dY, ld_dy, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db,
+                                      slabs, &c.jobs->back(), c.s);
+}
 
 // The x_embedding MLP depends only on x (forward) / on d(cat)[:, 0:H] (backward): five to eight small,
 // latency-bound launches that overlap perfectly with the edge-sized work of the main chain.  They run on a
@@ -125,6 +149,7 @@ static Ctx side_ctx(const Ctx& c, hipStream_t side) {
   x.s = side;
   x.y.bn_scratch = c.y.bn_scratch_x;
   x.y.dT1 = c.y.dT1x; x.y.dT2 = c.y.dT2x; x.y.slabs = c.y.slabs_x;
+  x.jobs = nullptr; x.slab_cursor = nullptr;
   return x;
 }
 
@@ -155,13 +180,10 @@ static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const 
   const int64_t H = y.H;
   ESC_TRY(esc_bn_bwd(w.Y1, H, out, ld_out, dOut, ld_dout, M, H, w.b1.mean, w.b1.invstd, p.bn1.gamma, p.bn1.beta, 1,
                      y.dT1, H, p.bn1.dgamma, p.bn1.dbeta, y.bn_scratch, c.s));
-  ESC_TRY(esc_linear_bwd_both(y.dT1, H, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1.w, H, M, H, H, y.dT2, H, 0, p.lin1.dw, H,
-                              p.lin1.db, y.slabs, c.s));
+  ESC_TRY(linear_backward(c, y.dT1, H, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1, M, y.dT2, H, 0));
   ESC_TRY(esc_bn_bwd(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, 1,
                      y.dT2, H, p.bn0.dgamma, p.bn0.dbeta, y.bn_scratch, c.s));
-  const int64_t K = p.lin0.in_dim;
-  return esc_linear_bwd_both(y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0.w, K, M, H, K, dA, ld_da, 0, p.lin0.dw, K,
-                             p.lin0.db, y.slabs, c.s);
+  return linear_backward(c, y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0);
 }
 
 static int forward(const Ctx& c) {
@@ -221,12 +243,10 @@ static int backward(const Ctx& c) {
   const Layout& y = c.y;
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W;
   // lin2 <- dpred
-  ESC_TRY(esc_linear_bwd_weight(y.dpred, 1, y.Yl, H, y.bl.scale, y.bl.shift, N, 1, H, m->lin2.dw, H, m->lin2.db, y.slabs, c.s));
-  ESC_TRY(esc_linear_bwd_input(y.dpred, 1, m->lin2.w, H, N, 1, H, y.dAl, H, 0, c.s));
+  ESC_TRY(linear_backward(c, y.dpred, 1, y.Yl, H, y.bl.scale, y.bl.shift, m->lin2, N, y.dAl, H, 0));
   ESC_TRY(esc_bn_bwd(y.Yl, H, nullptr, 0, y.dAl, H, N, H, y.bl.mean, y.bl.invstd, m->bn_lin1.gamma, m->bn_lin1.beta, 1,
                      y.dAl, H, m->bn_lin1.dgamma, m->bn_lin1.dbeta, y.bn_scratch, c.s));
-  ESC_TRY(esc_linear_bwd_both(y.dAl, H, y.cat, W, nullptr, nullptr, m->lin1.w, W, N, H, W, y.dcat, W, 0, m->lin1.dw, W,
-                              m->lin1.db, y.slabs, c.s));
+  ESC_TRY(linear_backward(c, y.dAl, H, y.cat, W, nullptr, nullptr, m->lin1, N, y.dcat, W, 0));
   // x_embedding backward (input x needs no gradient): only reads d(cat)[:, 0:H] -> side stream
   SideStream& ss = side_stream();
   if (ss.ok) {
@@ -251,27 +271,22 @@ static int backward(const Ctx& c) {
                                    y.d_e, C, dx, W, 1, y.deps_part, c.s));
     ESC_TRY(esc_reduce_sum(y.deps_part, N, cv.deps, c.s));
     if (g_materialise_edge_act)
-      ESC_TRY(esc_linear_bwd_both(y.d_e, C, y.Zemb, H, nullptr, nullptr, cv.lin.w, H, E, C, H, y.dZemb, H,
-                                  l == (int)L - 1 ? 0 : 1, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
+      ESC_TRY(linear_backward(c, y.d_e, C, y.Zemb, H, nullptr, nullptr, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
     else
-      ESC_TRY(esc_linear_bwd_both(y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin.w, H, E, C, H, y.dZemb, H,
-                                  l == (int)L - 1 ? 0 : 1, cv.lin.dw, H, cv.lin.db, y.slabs, c.s));
+      ESC_TRY(linear_backward(c, y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
   }
   if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
   // z_embedding + bag
   const bool mat = g_materialise_edge_act != 0;
   ESC_TRY(esc_bn_bwd(y.Yz, H, mat ? y.Zemb : nullptr, H, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma,
                      m->zbn1.beta, 1, y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, y.bn_scratch, c.s));
-  if (mat)
-    ESC_TRY(esc_linear_bwd_both(y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin.w, H, E, H, H, y.dAz, H, 0, m->zlin.dw, H,
-                                m->zlin.db, y.slabs, c.s));
-  else
-    ESC_TRY(esc_linear_bwd_both(y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin.w, H, E, H, H, y.dAz, H, 0, m->zlin.dw,
-                                H, m->zlin.db, y.slabs, c.s));
+  if (mat) ESC_TRY(linear_backward(c, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
+  else     ESC_TRY(linear_backward(c, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
   ESC_TRY(esc_bn_bwd(y.Zb, H, mat ? y.A0 : nullptr, H, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, y.bn_scratch, c.s));
   ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
                             y.bag_scratch, c.s));
+  if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
   if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_b, 0) != hipSuccess) {
     set_error("esc_engine: side-stream join failed");
     return ESC_ELAUNCH;
@@ -316,6 +331,10 @@ int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float
   if (rc) return rc;
   ESC_REQUIRE(loss, "esc_engine_train_step: null loss pointer");
   Ctx c{m, b, plan_layout(m, b->N, b->E, b->Z, workspace, true), stream, true};
+  std::vector<esc_reduce_job> jobs;
+  jobs.reserve(ESC_MAX_REDUCE_JOBS);
+  float* cursor = c.y.slabs;
+  if (3 * m->num_layers + 6 <= ESC_MAX_REDUCE_JOBS) { c.jobs = &jobs; c.slab_cursor = &cursor; }
   ESC_TRY(forward(c));
   ESC_TRY(esc_l1_loss(c.y.pred, b->y, b->N, loss_denom > 0 ? loss_denom : b->N, 1.0f, loss, c.y.dpred, stream));
   if (pred) {

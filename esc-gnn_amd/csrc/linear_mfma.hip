@@ -462,6 +462,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// every weight gradient of a training step reduced in ONE launch (the slabs are only needed by the optimiser):
+// block b belongs to the job whose [block_start, block_start+blocks) range contains it
+struct ReduceJobs {
+  esc_reduce_job job[ESC_MAX_REDUCE_JOBS];
+  int block_start[ESC_MAX_REDUCE_JOBS + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceJobs t) {
+  int j = 0;
+  while (j + 1 < t.count && (int)blockIdx.x >= t.block_start[j + 1]) ++j;
+  const esc_reduce_job& q = t.job[j];
+  const int64_t i = (int64_t)(blockIdx.x - t.block_start[j]) * blockDim.x + threadIdx.x;
+  if (i < q.n) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < q.splits; ++k) s += q.slabs[(size_t)k * q.n + i];
+    q.dw[(i / q.cols) * q.ld_dw + (i % q.cols)] = s;
+  } else if (q.db != nullptr && i - q.n < q.rows) {
+    const int64_t r = i - q.n;
+    float s = 0.f;
+    for (int k = 0; k < q.splits; ++k) s += q.db_part[(size_t)k * q.rows + r];
+    q.db[r] = s;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB, int KW = 1>
 static void launch_tile(const GemmArgs& g, int splits, hipStream_t s) {
   constexpr int NTHR = WM * WN * KW * 64;
@@ -623,10 +648,26 @@ int64_t esc_linear_bwd_weight_scratch(int64_t M, int64_t N, int64_t K) {
   return (cdiv(M, 128) + 1) * (N * K + N);
 }
 
+static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
+                       const float* in_shift, int64_t M, int64_t N, int64_t K, float* dW, int64_t ld_dw, float* db,
+                       float* slabs, esc_reduce_job* defer, void* stream);
+
 int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x,
                           const float* in_scale, const float* in_shift, int64_t M, int64_t N,
                           int64_t K, float* dW, int64_t ld_dw, float* db, float* slabs,
                           void* stream) {
+  return weight_impl(dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, dW, ld_dw, db, slabs, nullptr, stream);
+}
+
+static void fill_job(esc_reduce_job* j, const float* slabs, int64_t n, int splits, int64_t cols, float* dW, int64_t ld_dw,
+                     const float* db_part, int64_t rows, float* db) {
+  j->slabs = slabs; j->n = n; j->splits = splits; j->cols = cols; j->dw = dW; j->ld_dw = ld_dw;
+  j->db_part = db_part; j->rows = rows; j->db = db;
+}
+
+static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
+                       const float* in_shift, int64_t M, int64_t N, int64_t K, float* dW, int64_t ld_dw, float* db,
+                       float* slabs, esc_reduce_job* defer, void* stream) {
   ESC_REQUIRE(dY && X && dW && slabs, "esc_linear_bwd_weight: null pointer");
   ESC_REQUIRE(M > 0 && N > 0 && K > 0 && ld_dy >= N && ld_x >= K && ld_dw >= K, "esc_linear_bwd_weight: bad sizes");
   ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_bwd_weight: in_scale/in_shift must come together");
@@ -647,6 +688,7 @@ int esc_linear_bwd_weight(const float* dY, int64_t ld_dy, const float* X, int64_
   else          { ESC_TILE_DISPATCH(id, false, false, false, true) }
   ESC_CHECK_LAUNCH("esc_linear_bwd_weight.tiles");
   const int64_t n = N * K;
+  if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, g.db_part, N, db); return ESC_OK; }
   esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
               splits, (int)K, dW, ld_dw, g.db_part, (int)N, db);
   ESC_CHECK_LAUNCH("esc_linear_bwd_weight.reduce");
@@ -672,13 +714,54 @@ static void launch_dual(const DualArgs& a, hipStream_t s) {
 
 extern "C" {
 
+static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
+                     const float* in_shift, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K,
+                     float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw, float* db,
+                     float* slabs, esc_reduce_job* defer, void* stream);
+
 int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
                         const float* in_shift, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K,
                         float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw, float* db,
                         float* slabs, void* stream) {
+  return both_impl(dY, ld_dy, X, ld_x, in_scale, in_shift, W, ld_w, M, N, K, dX, ld_dx, accumulate, dW, ld_dw, db, slabs,
+                   nullptr, stream);
+}
+
+/* same, but the ordered slab reduce is NOT launched: its description is returned in *job for esc_slab_reduce_jobs.
+ * `slabs` must then stay untouched until that call. */
+int esc_linear_bwd_both_deferred(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
+                                 const float* in_shift, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K,
+                                 float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw, float* db,
+                                 float* slabs, esc_reduce_job* job, void* stream) {
+  ESC_REQUIRE(job, "esc_linear_bwd_both_deferred: null job");
+  return both_impl(dY, ld_dy, X, ld_x, in_scale, in_shift, W, ld_w, M, N, K, dX, ld_dx, accumulate, dW, ld_dw, db, slabs,
+                   job, stream);
+}
+
+int esc_slab_reduce_jobs(const esc_reduce_job* jobs, int count, void* stream) {
+  ESC_REQUIRE(jobs && count > 0 && count <= ESC_MAX_REDUCE_JOBS, "esc_slab_reduce_jobs: 1..%d jobs", ESC_MAX_REDUCE_JOBS);
+  ReduceJobs t{};
+  t.count = count;
+  int blocks = 0;
+  for (int j = 0; j < count; ++j) {
+    ESC_REQUIRE(jobs[j].slabs && jobs[j].dw && jobs[j].n > 0 && jobs[j].splits > 0, "esc_slab_reduce_jobs: bad job %d", j);
+    t.job[j] = jobs[j];
+    t.block_start[j] = blocks;
+    blocks += (int)cdiv(jobs[j].n + (jobs[j].db ? jobs[j].rows : 0), 256);
+  }
+  t.block_start[count] = blocks;
+  esc::launch(ESC_K_LINEAR, slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+  ESC_CHECK_LAUNCH("esc_slab_reduce_jobs");
+  return ESC_OK;
+}
+
+static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
+                     const float* in_shift, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K,
+                     float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw, float* db,
+                     float* slabs, esc_reduce_job* defer, void* stream) {
   ESC_REQUIRE(dY && X && W && dW && slabs, "esc_linear_bwd_both: null pointer");
   if (dX == nullptr || N <= 32 || K <= 32) {             // narrow shapes keep their dedicated tiles
-    int rc = esc_linear_bwd_weight(dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, dW, ld_dw, db, slabs, stream);
+    int rc = weight_impl(dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, dW, ld_dw, db, slabs, defer, stream);
     if (rc || dX == nullptr) return rc;
     return esc_linear_bwd_input(dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate, stream);
   }
@@ -712,6 +795,7 @@ int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t 
   else               { if (in_scale) launch_dual<64, 64, 2, 2, 64, true>(a, s); else launch_dual<64, 64, 2, 2, 64, false>(a, s); }
   ESC_CHECK_LAUNCH("esc_linear_bwd_both.tiles");
   const int64_t n = N * K;
+  if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, w.db_part, N, db); return ESC_OK; }
   esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
               splits, (int)K, dW, ld_dw, w.db_part, (int)N, db);
   ESC_CHECK_LAUNCH("esc_linear_bwd_both.reduce");

@@ -118,6 +118,21 @@ int esc_linear_bwd_both(const float* dY, int64_t ld_dy, const float* X, int64_t 
                         int64_t M, int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate,
                         float* dW, int64_t ld_dw, float* db, float* slabs, void* stream);
 
+/* deferred form: the tiles run now, the ordered slab reduce is described in *job; esc_slab_reduce_jobs then
+ * finishes up to ESC_MAX_REDUCE_JOBS weight gradients in ONE launch (they are only needed by the optimiser).
+ * Each deferred call needs its own `slabs` region, untouched until the reduce. */
+#define ESC_MAX_REDUCE_JOBS 48
+typedef struct esc_reduce_job {
+  const float* slabs; int64_t n; int32_t splits; int64_t cols; float* dw; int64_t ld_dw;
+  const float* db_part; int64_t rows; float* db;
+} esc_reduce_job;
+int esc_linear_bwd_both_deferred(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x,
+                                 const float* in_scale, const float* in_shift, const float* W, int64_t ld_w,
+                                 int64_t M, int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate,
+                                 float* dW, int64_t ld_dw, float* db, float* slabs, esc_reduce_job* job,
+                                 void* stream);
+int esc_slab_reduce_jobs(const esc_reduce_job* jobs /* host array */, int count, void* stream);
+
 /* ---- BatchNorm1d (training statistics) + ReLU, torch.nn.BatchNorm1d call sites
  * run_graphcount.py:55-60,66-72,80-87,115 --------------------------------------------------
  * `relu` arguments below select the fused activation: 0 none, 1 ReLU, 2 ELU(alpha=1) (zinc_models.py:513-522).
