@@ -53,12 +53,14 @@ SIGNATURES = {
     "esc_slab_reduce_jobs": [P, I32, P],
     "esc_bn_scratch": [I64],
     "esc_bn_stats": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P, P],
+    "esc_bn_stats_from_partials": [P, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P],
     "esc_bn_apply": [P, I64, I64, I64, P, P, P, P, I32, P, I64, P],
     "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, I64, P, P, P, P],
     "esc_affine_act": [P, I64, I64, I64, P, P, I32, P, I64, P],
     "esc_bn_eval_coef": [P, P, P, P, F32, I64, P, P, P],
     "esc_engine_set_side_stream": [I32],
     "esc_engine_set_materialise_edge_act": [I32],
+    "esc_engine_set_gemm_stats": [I32],
     "esc_engine_workspace_floats": [P, I64, I64, I64],
     "esc_engine_train_step": [P, P, P, I64, P, P, P],
     "esc_engine_predict": [P, P, P, P, P],

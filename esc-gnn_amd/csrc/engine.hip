@@ -41,6 +41,7 @@ struct Layout {
   // backward scratch
   float *dcat, *dAl, *dT1, *dT2, *dagg, *d_e, *dZemb, *dAz, *deps_part;
   float *bn_scratch, *bag_scratch, *slabs;
+  float *col_stats;               // GEMM-epilogue BatchNorm partials: float2[ceil(rows/32)][H]
   // private scratch of the x_embedding branch (runs on a side stream next to the z/conv chain)
   float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
   int64_t total;
@@ -67,6 +68,7 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   y.pred = a.take(N); y.dpred = a.take(N);
   y.bn_scratch = a.take(esc_bn_scratch(H));
   y.bn_scratch_x = a.take(esc_bn_scratch(H));
+  y.col_stats = a.take(2 * ((E > N ? E : N) / 32 + 1) * H);
   if (train) {
     y.dT1x = a.take(N * H); y.dT2x = a.take(N * H);
     y.slabs_x = a.take(esc_linear_bwd_weight_scratch(N, H, H));
@@ -153,6 +155,23 @@ static Ctx side_ctx(const Ctx& c, hipStream_t side) {
   return x;
 }
 
+static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's epilogue (no extra pass over Y)
+
+// Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
+static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linear_t& lin, const float* sc, const float* sh,
+                     int64_t M, float* Y, const esc_bn_t& bn, const BnWs& w) {
+  const int64_t H = c.y.H, K = lin.in_dim;
+  const bool fused = c.train && g_gemm_stats && H > 32 && c.jobs != nullptr;   // main chain only (col_stats is shared scratch)
+  ESC_TRY(esc_linear_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, fused ? c.y.col_stats : nullptr, c.s));
+  if (fused)
+    return esc_bn_stats_from_partials(c.y.col_stats, M, H, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean,
+                                      bn.running_var, bn.gamma, bn.beta, w.scale, w.shift, c.s);
+  if (c.train)
+    return esc_bn_stats(Y, H, M, H, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma,
+                        bn.beta, w.scale, w.shift, c.y.bn_scratch, c.s);
+  return esc_bn_eval_coef(bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, H, w.scale, w.shift, c.s);
+}
+
 static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const esc_bn_t& bn, const BnWs& w) {
   const int64_t C = c.y.H;
   if (c.train)
@@ -165,10 +184,8 @@ static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const 
 static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
                        float* out, int64_t ld_out) {
   const int64_t H = c.y.H;
-  ESC_TRY(esc_linear_fwd(A, ld_a, p.lin0.w, p.lin0.in_dim, p.lin0.b, nullptr, nullptr, M, H, p.lin0.in_dim, w.Y0, H, nullptr, c.s));
-  ESC_TRY(bn_coeffs(c, w.Y0, H, M, p.bn0, w.b0));
-  ESC_TRY(esc_linear_fwd(w.Y0, H, p.lin1.w, H, p.lin1.b, w.b0.scale, w.b0.shift, M, H, H, w.Y1, H, nullptr, c.s));
-  ESC_TRY(bn_coeffs(c, w.Y1, H, M, p.bn1, w.b1));
+  ESC_TRY(linear_bn(c, A, ld_a, p.lin0, nullptr, nullptr, M, w.Y0, p.bn0, w.b0));
+  ESC_TRY(linear_bn(c, w.Y0, H, p.lin1, w.b0.scale, w.b0.shift, M, w.Y1, p.bn1, w.b1));
   return esc_affine_act(w.Y1, H, M, H, w.b1.scale, w.b1.shift, 1, out, ld_out, c.s);
 }
 
@@ -197,11 +214,10 @@ static int forward(const Ctx& c) {
   const bool mat = g_materialise_edge_act != 0;
   if (mat) {
     ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, c.s));
-    ESC_TRY(esc_linear_fwd(y.A0, H, m->zlin.w, H, m->zlin.b, nullptr, nullptr, E, H, H, y.Yz, H, nullptr, c.s));
+    ESC_TRY(linear_bn(c, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
   } else {
-    ESC_TRY(esc_linear_fwd(y.Zb, H, m->zlin.w, H, m->zlin.b, y.zb0.scale, y.zb0.shift, E, H, H, y.Yz, H, nullptr, c.s));
-  }
-  ESC_TRY(bn_coeffs(c, y.Yz, H, E, m->zbn1, y.zb1));                      // z_emb = relu(Yz*scale+shift)
+    ESC_TRY(linear_bn(c, y.Zb, H, m->zlin, y.zb0.scale, y.zb0.shift, E, y.Yz, m->zbn1, y.zb1));
+  }                                                                       // z_emb = relu(Yz*scale+shift)
   if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, c.s));
   // xs[0] = x_embedding(x) (reference :166) — side stream
   SideStream& ss = side_stream();
@@ -232,8 +248,7 @@ static int forward(const Ctx& c) {
     set_error("esc_engine: side-stream join failed");
     return ESC_ELAUNCH;
   }
-  ESC_TRY(esc_linear_fwd(y.cat, W, m->lin1.w, W, m->lin1.b, nullptr, nullptr, N, H, W, y.Yl, H, nullptr, c.s));
-  ESC_TRY(bn_coeffs(c, y.Yl, H, N, m->bn_lin1, y.bl));
+  ESC_TRY(linear_bn(c, y.cat, W, m->lin1, nullptr, nullptr, N, y.Yl, m->bn_lin1, y.bl));
   return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
 }
 
@@ -312,6 +327,11 @@ extern "C" {
 
 int esc_engine_set_side_stream(int on) {
   g_use_side_stream = on != 0;
+  return ESC_OK;
+}
+
+int esc_engine_set_gemm_stats(int on) {
+  g_gemm_stats = on != 0;
   return ESC_OK;
 }
 

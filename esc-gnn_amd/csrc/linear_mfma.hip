@@ -223,6 +223,7 @@ struct GemmArgs {
   const float* pro_scale;   // prologue affine (applies to A if A_KC: per k; to B if !B_KC && !A_KC: per col)
   const float* pro_shift;
   float* db_part;           // weight grad: per-split column sums of A' (= dY)   [splits][rowsC]
+  float2* col_stats;        // forward: per 32-row block (mean, M2) of the outputs, [ceil(rowsC/32)][colsC]
   int rowsC, colsC, red;    // output rows, output cols, reduction length
   int red_per_split;
   int accumulate;
@@ -391,6 +392,37 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(size_t)q * TILE_F + ((i * NT + j) * 16 + r) * 64 + l];
+  }
+  // ---- optional BatchNorm statistics of the OUTPUT (bias included), one (mean, M2) pair per column and per
+  // 32-row block, merged later by Chan's formula (esc_bn_stats_from_partials): the following BatchNorm needs no
+  // extra pass over Y.  Lane halves hold rows 4h..4h+3 (+8k): one cross-half shuffle completes a column.
+  if (g.col_stats != nullptr) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * TN + j * 32 + (l & 31);
+        const int row0 = m0 + wm * TM + i * 32;
+        const float bv = (g.bias && col < g.colsC) ? g.bias[col] : 0.f;
+        const int nvalid = min(32, g.rowsC - row0);
+        float s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+          if (row < g.rowsC) s1 += acc[i][j][r] + bv;
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = nvalid > 0 ? s1 / (float)nvalid : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+          if (row < g.rowsC) { const float d = acc[i][j][r] + bv - mean; m2 = fmaf(d, d, m2); }
+        }
+        m2 += __shfl_xor(m2, 32, 64);
+        if (l < 32 && col < g.colsC && nvalid > 0)
+          g.col_stats[(size_t)(row0 / 32) * g.colsC + col] = make_float2(mean, m2);
+      }
   }
   // ---- epilogue: C/D map of the 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Cbase = g.C + (g.c_slab ? (size_t)split * g.rowsC * g.ldc : 0);
@@ -583,18 +615,20 @@ int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, c
   ESC_REQUIRE(X && W && Y, "esc_linear_fwd: null pointer");
   ESC_REQUIRE(M >= 0 && N > 0 && K > 0 && ld_x >= K && ld_w >= K && ld_y >= N, "esc_linear_fwd: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
   ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_fwd: in_scale/in_shift must come together");
-  ESC_REQUIRE(col_stats == nullptr, "esc_linear_fwd: col_stats not supported in this ABI revision");
+  ESC_REQUIRE(col_stats == nullptr || N > 32, "esc_linear_fwd: col_stats needs N > 32");
   ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_fwd: dimension too large");
   if (M == 0) return ESC_OK;
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g{};
   g.A = X; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.C = Y; g.ldc = ld_y; g.bias = bias;
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.db_part = nullptr;
+  g.col_stats = reinterpret_cast<float2*>(col_stats);
   g.rowsC = (int)M; g.colsC = (int)N; g.red = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
   g.a_vec = vec_ok(X, ld_x) && (!in_scale || (aligned16(in_scale) && aligned16(in_shift)));
   g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
   const int splits = 1;
-  const int id = (N <= 32) ? 2 : (M >= 8192 ? g_knob[KNOB_FWD_BIG] : g_knob[KNOB_FWD_SMALL]);
+  int id = (N <= 32) ? 2 : (M >= 8192 ? g_knob[KNOB_FWD_BIG] : g_knob[KNOB_FWD_SMALL]);
+  if (col_stats && id >= 8) id = 4;          // in-workgroup split-K tiles keep partial sums per wave group
   if (in_scale) { ESC_TILE_DISPATCH(id, true, true, true, false) }
   else          { ESC_TILE_DISPATCH(id, true, true, false, false) }
   ESC_CHECK_LAUNCH("esc_linear_fwd");

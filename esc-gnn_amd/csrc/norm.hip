@@ -69,7 +69,8 @@ __device__ __forceinline__ void chan_merge(double& n, double& mu, double& m2, do
 
 // one wave per column: lanes own slots lane, lane+64, ... then a shuffle-tree merge (fixed order)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restrict__ partial, int M, int C, int P,
-                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          int block_rows, float eps, float momentum,
+                                                          float* __restrict__ mean,
                                                           float* __restrict__ invstd,
                                                           float* __restrict__ running_mean,
                                                           float* __restrict__ running_var,
@@ -80,9 +81,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restri
   if (c >= C) return;
   const int lane = lane_id();
   double n = 0.0, mu = 0.0, m2 = 0.0;
-  for (int p = lane; p < P && p < M; p += 64) {
+  // block_rows == 0: slot p owns rows p, p+P, ... (bn_partial_kernel); else slot p owns rows [p*block_rows, ...)
+  for (int p = lane; p < P && (block_rows > 0 || p < M); p += 64) {
     const float2 v = partial[(size_t)p * C + c];
-    chan_merge(n, mu, m2, (double)((M - p + P - 1) / P), (double)v.x, (double)v.y);
+    const int np = block_rows > 0 ? min(block_rows, M - p * block_rows) : (M - p + P - 1) / P;
+    chan_merge(n, mu, m2, (double)np, (double)v.x, (double)v.y);
   }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -296,8 +299,21 @@ int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, 
   const int rb = rowblocks(M);
   esc::launch(ESC_K_NORM, bn_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
   ESC_CHECK_LAUNCH("esc_bn_stats.partial");
-  esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, eps, momentum, mean, invstd, running_mean, running_var, gamma, beta, scale, shift);
+  esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, 0, eps, momentum, mean, invstd, running_mean, running_var, gamma, beta, scale, shift);
   ESC_CHECK_LAUNCH("esc_bn_stats.finalize");
+  return ESC_OK;
+}
+
+int esc_bn_stats_from_partials(const float* partials, int64_t M, int64_t C, float eps, float momentum, float* mean,
+                                float* invstd, float* running_mean, float* running_var, const float* gamma,
+                                const float* beta, float* scale, float* shift, void* stream) {
+  ESC_REQUIRE(partials && mean && invstd, "esc_bn_stats_from_partials: null pointer");
+  ESC_REQUIRE(M > 1 && C > 0 && M < (1LL << 31), "esc_bn_stats_from_partials: need more than 1 row per channel");
+  ESC_REQUIRE((scale == nullptr) == (shift == nullptr), "esc_bn_stats_from_partials: scale/shift must come together");
+  esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream,
+              (const float2*)partials, (int)M, (int)C, (int)cdiv(M, 32), 32, eps, momentum, mean, invstd, running_mean,
+              running_var, gamma, beta, scale, shift);
+  ESC_CHECK_LAUNCH("esc_bn_stats_from_partials");
   return ESC_OK;
 }
 

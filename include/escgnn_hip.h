@@ -86,8 +86,9 @@ int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream);
  * torch.nn.Linear call sites run_graphcount.py:54-121,183-189 (+ GINEConv.lin).
  * Y[M,N] = act(X)[M,K] * W[N,K]^T + bias[N]   (bias may be NULL)
  * act(X) = X, or relu(X*in_scale[k] + in_shift[k]) when in_scale != NULL (fused BN+ReLU of the
- * producer layer).  col_stats (may be NULL): float[ceil(M/128)][2][N] per-row-tile partial
- * (sum, sum of squares) of Y for a following BatchNorm. */
+ * producer layer).  col_stats (may be NULL; needs N > 32): float2[ceil(M/32)][N] — per 32-row block the (mean, M2)
+ * of every output column, written by the GEMM epilogue so that the BatchNorm that follows needs no pass over Y
+ * (finish with esc_bn_stats_from_partials). */
 int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
                    const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                    float* Y, int64_t ld_y, float* col_stats, void* stream);
@@ -145,6 +146,11 @@ int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, 
                  float* mean, float* invstd, float* running_mean, float* running_var,
                  const float* gamma, const float* beta, float* scale, float* shift,
                  float* scratch, void* stream);
+/* same outputs as esc_bn_stats, from the per-32-row (mean, M2) partials a forward GEMM left in col_stats */
+int esc_bn_stats_from_partials(const float* partials, int64_t M, int64_t C, float eps, float momentum,
+                               float* mean, float* invstd, float* running_mean, float* running_var,
+                               const float* gamma, const float* beta, float* scale, float* shift,
+                               void* stream);
 int esc_bn_apply(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* mean,
                  const float* invstd, const float* gamma, const float* beta, int relu, float* Y,
                  int64_t ld_y, void* stream);
@@ -204,6 +210,8 @@ int esc_engine_set_side_stream(int on);
 /* 1 (default): write relu(BN(.)) of the two EDGE-sized z_embedding activations once instead of re-applying the
  * affine+ReLU prologue in every consumer GEMM; 0: fully fused (less memory, slower on MI355X r01). */
 int esc_engine_set_materialise_edge_act(int on);
+/* 1 (default): BatchNorm statistics come from the producing GEMM's epilogue (col_stats) instead of a pass over Y */
+int esc_engine_set_gemm_stats(int on);
 int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z);
 /* loss[0] = sum|pred-y| / loss_denom (loss_denom <= 0: N).  pred (may be NULL): float[N]. */
 int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
