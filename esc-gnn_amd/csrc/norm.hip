@@ -57,6 +57,83 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   partial[(size_t)slot * C + c] = out;
 }
 
+// float4 variants (C % 4 == 0, 16-B aligned rows): a wave covers 256 columns with one 1-KiB load per row, so a
+// few rows per wave already put tens of KiB in flight per CU — the scalar form above tops out near 1 TB/s on the
+// edge-sized tensors.
+__global__ __launch_bounds__(256) void bn_partial_kernel_v4(const float* __restrict__ X, int64_t ld, int M, int C,
+                                                            float2* __restrict__ partial) {
+  const int c = (blockIdx.x * 64 + lane_id()) * 4;
+  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int P = gridDim.y * 4;
+  if (c >= C) return;
+  float4 shift = make_float4(0.f, 0.f, 0.f, 0.f), s1 = shift, s2 = shift;
+  int n = 0;
+  if (slot < M) shift = *reinterpret_cast<const float4*>(X + (size_t)slot * ld + c);
+#pragma unroll 8
+  for (int r = slot; r < M; r += P) {
+    const float4 v = *reinterpret_cast<const float4*>(X + (size_t)r * ld + c);
+    const float dx = v.x - shift.x, dy = v.y - shift.y, dz = v.z - shift.z, dw = v.w - shift.w;
+    s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+    s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+    ++n;
+  }
+  float2 o[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  if (n > 0) {
+    const float sh[4] = {shift.x, shift.y, shift.z, shift.w}, a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double m = (double)a1[t] / n;
+      o[t] = make_float2((float)((double)sh[t] + m), (float)fmax((double)a2[t] - (double)a1[t] * m, 0.0));
+    }
+  }
+  float2* dst = partial + (size_t)slot * C + c;
+  *reinterpret_cast<float4*>(dst) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+  *reinterpret_cast<float4*>(dst + 2) = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+}
+
+// ACT / HAS_Y are compile-time so that every load in the row loop is unconditional (a run-time select around a
+// load makes hipcc branch and wait per element, which is what kept the scalar kernel at ~1 TB/s)
+template <int ACT, bool HAS_Y>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __restrict__ X, int64_t ldx,
+                                                                const float* __restrict__ Y, int64_t ldy,
+                                                                const float* __restrict__ dY, int64_t ldg, int M,
+                                                                int C, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float2* __restrict__ partial) {
+  constexpr int relu = ACT;
+  const int c = (blockIdx.x * 64 + lane_id()) * 4;
+  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int P = gridDim.y * 4;
+  if (c >= C) return;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+  const float4 ga = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 be = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
+  for (int r = slot; r < M; r += P) {
+    float4 g = *reinterpret_cast<const float4*>(dY + (size_t)r * ldg + c);
+    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
+    const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
+    if constexpr (ACT != 0) {
+      if constexpr (HAS_Y) {
+        const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+        g.x *= act_grad_from_out(y.x, relu); g.y *= act_grad_from_out(y.y, relu);
+        g.z *= act_grad_from_out(y.z, relu); g.w *= act_grad_from_out(y.w, relu);
+      } else {
+        g.x *= act_grad_from_pre(fmaf(xh.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(fmaf(xh.y, ga.y, be.y), relu);
+        g.z *= act_grad_from_pre(fmaf(xh.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(fmaf(xh.w, ga.w, be.w), relu);
+      }
+    }
+    s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+    s2.x = fmaf(g.x, xh.x, s2.x); s2.y = fmaf(g.y, xh.y, s2.y); s2.z = fmaf(g.z, xh.z, s2.z); s2.w = fmaf(g.w, xh.w, s2.w);
+  }
+  float2* dst = partial + (size_t)slot * C + c;
+  *reinterpret_cast<float4*>(dst) = make_float4(s1.x, s2.x, s1.y, s2.y);
+  *reinterpret_cast<float4*>(dst + 2) = make_float4(s1.z, s2.z, s1.w, s2.w);
+}
+
 // Chan/Welford merge of two (count, mean, M2) partials
 __device__ __forceinline__ void chan_merge(double& n, double& mu, double& m2, double nb, double mub, double m2b) {
   if (nb == 0.0) return;
@@ -194,16 +271,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __re
   }
 }
 
-template <int VEC>
+template <int VEC, int ACT, bool HAS_Y>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ X, int64_t ldx,
                                                            const float* __restrict__ Y, int64_t ldy,
                                                            const float* __restrict__ dY, int64_t ldg, int64_t M,
                                                            int C, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int relu,
+                                                           const float* __restrict__ beta,
                                                            const float2* __restrict__ coef,
                                                            float* __restrict__ dX, int64_t ldd) {
+  constexpr int relu = ACT;
   const int cv = C / VEC;
   const int64_t total = M * cv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -215,22 +293,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float4 g = *reinterpret_cast<const float4*>(dY + r * ldg + c);
       xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
       gv[0] = g.x; gv[1] = g.y; gv[2] = g.z; gv[3] = g.w;
-      if (relu && Y) {
+      if constexpr (ACT != 0 && HAS_Y) {
         const float4 y = *reinterpret_cast<const float4*>(Y + r * ldy + c);
         yv[0] = y.x; yv[1] = y.y; yv[2] = y.z; yv[3] = y.w;
       }
     } else {
       xv[0] = X[r * ldx + c];
       gv[0] = dY[r * ldg + c];
-      if (relu && Y) yv[0] = Y[r * ldy + c];
+      if constexpr (ACT != 0 && HAS_Y) yv[0] = Y[r * ldy + c];
     }
 #pragma unroll
     for (int t = 0; t < VEC; ++t) {
       const float is = invstd[c + t];
       const float xh = (xv[t] - mean[c + t]) * is;
       float g = gv[t];
-      if (relu) g *= Y ? act_grad_from_out(yv[t], relu)
-                       : act_grad_from_pre(fmaf(xh, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f), relu);
+      if constexpr (ACT != 0) {
+        if constexpr (HAS_Y) g *= act_grad_from_out(yv[t], relu);
+        else g *= act_grad_from_pre(fmaf(xh, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f), relu);
+      }
       const float2 k = coef[c + t];
       ov[t] = (gamma ? gamma[c + t] : 1.f) * is * (g - k.x - xh * k.y);
     }
@@ -278,7 +358,12 @@ __global__ __launch_bounds__(256) void bn_eval_coef_kernel(const float* __restri
   shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
 }
 
-static inline int rowblocks(int64_t M) { return (int)(M < 4 * NORM_ROWBLOCKS ? cdiv(M, 4) : NORM_ROWBLOCKS); }
+// >= 4 rows per wave slot (scalar kernels keep the old 64-block cap: their finalize cost grows with the slot count)
+static inline int rowblocks(int64_t M, bool wide) {
+  const int64_t cap = wide ? NORM_ROWBLOCKS : 64;
+  const int64_t want = cdiv(M, 16);
+  return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
 
 }  // namespace esc
 
@@ -296,8 +381,10 @@ int esc_bn_stats(const float* X, int64_t ld_x, int64_t M, int64_t C, float eps, 
   ESC_REQUIRE(X && mean && invstd && scratch, "esc_bn_stats: null pointer");
   ESC_REQUIRE(M > 1 && C > 0 && ld_x >= C && M < (1LL << 31), "esc_bn_stats: need more than 1 row per channel (M=%ld, C=%ld)", (long)M, (long)C);
   hipStream_t s = (hipStream_t)stream;
-  const int rb = rowblocks(M);
-  esc::launch(ESC_K_NORM, bn_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
+  const bool wide = (C % 4 == 0) && (ld_x % 4 == 0) && aligned16(X) && aligned16(scratch);
+  const int rb = rowblocks(M, wide);
+  if (wide) esc::launch(ESC_K_NORM, bn_partial_kernel_v4, dim3((unsigned)cdiv(C, 256), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
+  else      esc::launch(ESC_K_NORM, bn_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, (float2*)scratch);
   ESC_CHECK_LAUNCH("esc_bn_stats.partial");
   esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, (const float2*)scratch, (int)M, (int)C, rb * 4, 0, eps, momentum, mean, invstd, running_mean, running_var, gamma, beta, scale, shift);
   ESC_CHECK_LAUNCH("esc_bn_stats.finalize");
@@ -365,10 +452,21 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   ESC_REQUIRE(X && dY && dX && mean && invstd && scratch, "esc_bn_bwd: null pointer");
   ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && (!Y || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  const int rb = rowblocks(M);
+  const bool wide = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (!Y || ld_y % 4 == 0) && aligned16(X) &&
+                    aligned16(dY) && (!Y || aligned16(Y)) && aligned16(mean) && aligned16(invstd) &&
+                    (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && aligned16(scratch);
+  const int rb = rowblocks(M, wide);
   float2* partial = (float2*)scratch;
   float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
-  esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, gamma, beta, partial);
+  if (wide) {
+    const dim3 grid((unsigned)cdiv(C, 256), rb);
+#define ESC_BWD_PARTIAL(A, H) esc::launch(ESC_K_NORM, bn_bwd_partial_kernel_v4<A, H>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial)
+    if (relu == 0)      ESC_BWD_PARTIAL(0, false);
+    else if (relu == 1) { if (Y) ESC_BWD_PARTIAL(1, true); else ESC_BWD_PARTIAL(1, false); }
+    else                { if (Y) ESC_BWD_PARTIAL(2, true); else ESC_BWD_PARTIAL(2, false); }
+#undef ESC_BWD_PARTIAL
+  }
+  else      esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, gamma, beta, partial);
   ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
   esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
   ESC_CHECK_LAUNCH("esc_bn_bwd.finalize");
@@ -377,8 +475,14 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
                    (!gamma || aligned16(gamma));
   const int64_t work = M * (vec ? C / 4 : C);
   const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
-  if (vec) esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, beta, relu, coef, dX, ld_dx);
-  else     esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, beta, relu, coef, dX, ld_dx);
+#define ESC_BWD_APPLY(V, A, H) esc::launch(ESC_K_NORM, bn_bwd_apply_kernel<V, A, H>, dim3(blocks), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, M, (int)C, mean, invstd, gamma, beta, coef, dX, ld_dx)
+#define ESC_BWD_APPLY_V(V)                                                                 \
+  if (relu == 0)      ESC_BWD_APPLY(V, 0, false);                                           \
+  else if (relu == 1) { if (Y) ESC_BWD_APPLY(V, 1, true); else ESC_BWD_APPLY(V, 1, false); } \
+  else                { if (Y) ESC_BWD_APPLY(V, 2, true); else ESC_BWD_APPLY(V, 2, false); }
+  if (vec) { ESC_BWD_APPLY_V(4) } else { ESC_BWD_APPLY_V(1) }
+#undef ESC_BWD_APPLY_V
+#undef ESC_BWD_APPLY
   ESC_CHECK_LAUNCH("esc_bn_bwd.apply");
   return ESC_OK;
 }
