@@ -69,10 +69,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the hot path has no CPU fallback")
+    local = local % torch.cuda.device_count()             # rehearsals may put several ranks on one card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1:                                         # RCCL over xGMI; ESC_DIST_BACKEND=gloo only for rehearsing on one GPU
+        backend = os.environ.get("ESC_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     import esc_gnn_amd as E
     from esc_gnn_amd import _native as nv
     from esc_gnn_amd.datasets import build_count_dataset

@@ -168,10 +168,12 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("run_graphcount: needs a HIP device (the hot path has no CPU fallback)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1:                                         # RCCL over xGMI; ESC_DIST_BACKEND=gloo only for rehearsing on one GPU
+        backend = os.environ.get("ESC_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 
     torch.manual_seed(args.seed)                          # reference :361-366
     torch.cuda.manual_seed_all(args.seed)
