@@ -98,6 +98,9 @@ template <int ROWS, int BK, int NTHR, bool PRO>
 __device__ __forceinline__ void finish_kcontig(int r0, int rows, float4 s4, float4 h4,
                                                float4 (&reg)[KContigTile<ROWS, BK, NTHR>::PER_THREAD]) {
   using T = KContigTile<ROWS, BK, NTHR>;
+  if constexpr (!PRO) {
+    if (r0 + ROWS <= rows) return;        // interior tile (block-uniform): nothing to mask, nothing to transform
+  }
   const int tid = threadIdx.x;
 #pragma unroll
   for (int p = 0; p < T::PER_THREAD; ++p) {
@@ -170,6 +173,9 @@ __device__ __forceinline__ void finish_redmajor(int k0, int kdim, float4 s4, flo
   const int tid = threadIdx.x;
   constexpr int QPR = COLS / 4;
   static_assert(NTHR % QPR == 0, "a thread keeps the same column quad for every pass");
+  if constexpr (!PRO) {
+    if (k0 + BK <= kdim) return;          // full K-step (block-uniform): nothing to mask
+  }
 #pragma unroll
   for (int p = 0; p < RedMajorTile<COLS, BK, NTHR>::PER_THREAD; ++p) {
     const int f = tid + p * NTHR;
