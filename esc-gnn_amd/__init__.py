@@ -22,11 +22,19 @@ __all__ = ["create_subgraphs", "create_subgraphs_many", "Data", "Batch", "DataLo
 def install_dropin():
     """Register this package's modules under the reference's top-level module names, so that an unmodified
     `from utils_edge_efficient import create_subgraphs`, `from batch import Batch`,
-    `from dataloader import DataLoader` or `from kernel.gin import NestedGIN_eff` resolves here."""
+    `from dataloader import DataLoader`, `from kernel.gin import NestedGIN_eff`, `from zinc_models import *`,
+    `from ogb_mol_gnn import GNN` or `from modules.gine_operations import GINEPLUS` resolves here."""
     import sys
     import types
-    from . import batch as _batch, dataloader as _dataloader, kernel_gin as _kernel_gin, utils_edge_efficient as _uee
+    from . import (batch as _batch, dataloader as _dataloader, kernel_gin as _kernel_gin, ogb_mol_gnn as _ogb,
+                   utils_edge_efficient as _uee, zinc_models as _zinc)
+    from .modules import gine_operations as _gine_ops
     sys.modules.setdefault("utils_edge_efficient", _uee)
+    sys.modules.setdefault("zinc_models", _zinc)
+    sys.modules.setdefault("ogb_mol_gnn", _ogb)
+    mods = sys.modules.setdefault("modules", types.ModuleType("modules"))
+    mods.gine_operations = _gine_ops
+    sys.modules.setdefault("modules.gine_operations", _gine_ops)
     sys.modules.setdefault("batch", _batch)
     sys.modules.setdefault("dataloader", _dataloader)
     pkg = sys.modules.setdefault("kernel", types.ModuleType("kernel"))

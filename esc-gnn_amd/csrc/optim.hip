@@ -28,6 +28,39 @@ __global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__
   }
 }
 
+// BCEWithLogitsLoss()(pred[is_labeled], y[is_labeled]) with is_labeled = (y == y): the OGB training criterion
+// (/root/reference/run_ogb_mol.py:65-72).  Single workgroup, fp64 accumulation, fixed order.
+__global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                          int64_t M, double denom_in, float* __restrict__ loss,
+                                                          float* __restrict__ dpred) {
+  __shared__ double sh[16];
+  __shared__ double shc[16];
+  double acc = 0.0, cnt = 0.0;
+  for (int64_t i = threadIdx.x; i < M; i += blockDim.x) {
+    const float t = y[i], x = pred[i];
+    if (t == t) {
+      acc += (double)(fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
+      cnt += 1.0;
+    }
+  }
+  acc = wave_sum(acc);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = acc; shc[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  double t = 0.0, c = 0.0;
+  for (int w = 0; w < 16; ++w) { t += sh[w]; c += shc[w]; }
+  const double denom = denom_in > 0.0 ? denom_in : c;
+  if (threadIdx.x == 0) loss[0] = denom > 0.0 ? (float)(t / denom) : 0.f;
+  if (dpred) {
+    const float inv = denom > 0.0 ? (float)(1.0 / denom) : 0.f;
+    for (int64_t i = threadIdx.x; i < M; i += blockDim.x) {
+      const float tt = y[i], x = pred[i];
+      const float sg = 1.f / (1.f + expf(-x));
+      dpred[i] = (tt == tt) ? (sg - tt) * inv : 0.f;
+    }
+  }
+}
+
 // torch.optim.Adam single-tensor arithmetic, in torch's operation order:
 //   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(bc2) + eps; p += -(lr/bc1) * m/denom
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -57,6 +90,15 @@ int esc_l1_loss(const float* pred, const float* y, int64_t M, int64_t denom, flo
   ESC_REQUIRE(M > 0 && denom > 0, "esc_l1_loss: empty batch");
   esc::launch(-1, l1_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, y, M, (double)denom, grad_scale, loss, dpred);
   ESC_CHECK_LAUNCH("esc_l1_loss");
+  return ESC_OK;
+}
+
+int esc_bce_logits_loss(const float* pred, const float* y, int64_t M, int64_t denom, float* loss, float* dpred,
+                        void* stream) {
+  ESC_REQUIRE(pred && y && loss, "esc_bce_logits_loss: null pointer");
+  ESC_REQUIRE(M > 0, "esc_bce_logits_loss: empty batch");
+  esc::launch(-1, bce_logits_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, y, M, (double)denom, loss, dpred);
+  ESC_CHECK_LAUNCH("esc_bce_logits_loss");
   return ESC_OK;
 }
 

@@ -259,6 +259,37 @@ def l1_loss(pred, y, denom=None):
     return _L1Loss.apply(pred, y, denom)
 
 
+class _BceLogits(Function):
+    """BCEWithLogitsLoss()(pred[is_labeled], y[is_labeled]), is_labeled = (y == y) (run_ogb_mol.py:65-72);
+    `denom` overrides the divisor (global labeled count under graph sharding)."""
+
+    @staticmethod
+    def forward(ctx, pred, y, denom):
+        _dev(pred, y)
+        _on(pred.device, y)
+        shape = pred.shape
+        pred = pred.contiguous().view(-1)
+        y = y.contiguous().view(-1).float()
+        if pred.numel() != y.numel():
+            raise ValueError("bce_with_logits_loss: %d predictions vs %d targets" % (pred.numel(), y.numel()))
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty(pred.numel(), dtype=torch.float32, device=pred.device)
+        nv.call("esc_bce_logits_loss", nv.ptr(pred), nv.ptr(y), pred.numel(), int(denom or 0), nv.ptr(loss), nv.ptr(dpred),
+                nv.stream())
+        ctx.save_for_backward(dpred)
+        ctx.shape = shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return (dpred * g).view(ctx.shape), None, None
+
+
+def bce_with_logits_loss(pred, y, denom=None):
+    return _BceLogits.apply(pred, y, denom)
+
+
 class _SegmentPool(Function):
     """global_add_pool / global_mean_pool (run_graphcount.py:179, zinc_models.py:602) over a sorted batch vector."""
 

@@ -1,0 +1,180 @@
+"""ZINC driver on the ESC hot path — the MI355X-native twin of /root/reference/run_zinc.py for
+`--model NestedGIN_eff` (BASELINE config 4): flags (:21-86), processed-name / feature settings (:161-176,
+`create_subgraphs_eff(g, h, use_rd, self_loop)` :141-146), target normalisation (:211-217), L1 training loop and
+"test when validation improves or every 10 epochs" logging (:279-339).
+
+data/zinc/raw/ZINC.pkl is absent (.MISSING_LARGE_BLOBS) and is a DGL pickle, so the default data are seeded
+ZINC-shaped molecules (datasets.synthetic_zinc_graphs).  The whole dataset lives in HBM (DeviceGraphStore); forward,
+loss, backward and Adam run through libescgnn_hip.so; under torchrun the global batch is sharded by graph.
+
+    python -m esc_gnn_amd.run_zinc --model NestedGIN_eff --h 3 --layers 6 --epochs 1000
+"""
+import torch
+
+from . import ops
+from .zinc_models import NestedGIN_eff
+
+_FLAGS = [  # same names, types and defaults as the reference CLI
+    ("--target", dict(default=0, type=int)),
+    ("--filter", dict(action="store_true", default=False)),
+    ("--convert", dict(type=str, default="post")),
+    ("--model", dict(type=str, default="NestedGIN_eff", help="NestedGIN_eff (GNN / NGNN / I2GNN baselines: out of scope)")),
+    ("--layers", dict(type=int, default=6)),
+    ("--h", dict(type=int, default=3)),
+    ("--max_nodes_per_hop", dict(type=int, default=None)),
+    ("--node_label", dict(type=str, default="spd")),
+    ("--use_rd", dict(action="store_true", default=True)),
+    ("--subgraph2_pooling", dict(default="mean-center-side")),
+    ("--subgraph_pooling", dict(default="mean-context")),
+    ("--use_pooling_nn", dict(action="store_true", default=False)),
+    ("--virtual_node", dict(action="store_true", default=False)),
+    ("--double_pooling", dict(action="store_true", default=True)),
+    ("--gate", dict(action="store_true", default=True)),
+    ("--epochs", dict(type=int, default=1000)),
+    ("--batch_size", dict(type=int, default=256)),
+    ("--lr", dict(type=float, default=1e-3)),
+    ("--lr_decay_factor", dict(type=float, default=0.95)),
+    ("--patience", dict(type=int, default=10)),
+    ("--drop_ratio", dict(type=float, default=0.0)),
+    ("--normalize_x", dict(action="store_true", default=False)),
+    ("--squared_dist", dict(action="store_true", default=False)),
+    ("--not_normalize_dist", dict(action="store_true", default=False)),
+    ("--use_max_dist", dict(action="store_true", default=False)),
+    ("--use_pos", dict(action="store_true", default=False)),
+    ("--RNI", dict(action="store_true", default=False)),
+    ("--use_relative_pos", dict(action="store_true", default=False)),
+    ("--self_loop", dict(action="store_true", default=False)),
+    ("--seed", dict(type=int, default=1)),
+    ("--save_appendix", dict(default="")),
+    ("--keep_old", dict(action="store_true", default=False)),
+    ("--dataset", dict(default="zinc")),
+    ("--load_model", dict(default=None)),
+    ("--eval", dict(default=0, type=int)),
+    ("--train_only", dict(default=0, type=int)),
+    # additions (not in the reference): size of the synthetic stand-in for the absent ZINC.pkl
+    ("--synthetic_graphs", dict(type=int, default=12000, help="train+val+test molecules (10:1:1 like ZINC-12k)")),
+]
+
+
+def build_parser():
+    import argparse
+    ap = argparse.ArgumentParser(description="ESC-GNN for ZINC graphs (MI355X hot path).")
+    for name, kw in _FLAGS:
+        ap.add_argument(name, **kw)
+    return ap
+
+
+def _load_splits(args):
+    from .datasets import build_feature_dataset, synthetic_zinc_graphs
+    G = args.synthetic_graphs
+    raw = synthetic_zinc_graphs(0, G)
+    done = build_feature_dataset(raw, args.h, use_rd=args.use_rd, self_loop=args.self_loop)     # reference :141-146
+    n_tr, n_va = (G * 10) // 12, G // 12
+    return done[:n_tr], done[n_tr:n_tr + n_va], done[n_tr + n_va:]
+
+
+def main(argv=None):
+    import os
+    import time
+
+    from .harness import Context, default_appendix, open_result_dir, seed_everything, sharded_batches
+    from .optim import FlatAdam, ReduceLROnPlateau
+    from .parallel import broadcast_parameters
+    from .store import DeviceGraphStore
+
+    args = build_parser().parse_args(argv)
+    if args.model != "NestedGIN_eff":
+        print("Error: no such model!")                    # reference :173-175 (baselines are not on the ESC path)
+        raise SystemExit(1)
+    if args.max_nodes_per_hop is not None:
+        raise NotImplementedError("max_nodes_per_hop: random neighbour sampling is outside the ESC hot path")
+    ctx = Context()
+    seed_everything(args.seed)
+    args.save_appendix = default_appendix(args.save_appendix)
+    args.res_dir = "results/" + args.dataset + "_" + args.model + args.save_appendix
+    cmd_input = open_result_dir(ctx, args.res_dir, ("run_zinc.py", "utils_edge_efficient.py", "zinc_models.py"))
+
+    t11 = time.time()
+    tr, va, te = _load_splits(args)
+    ctx.say("Preprocessing time cost: {}s,".format(time.time() - t11))
+    y_train_val = torch.cat([d.y for d in tr + va], dim=0)                 # reference :211-217
+    mean, std = y_train_val.mean(dim=0), y_train_val.std(dim=0)
+    for part in (tr, va, te):
+        for d in part:
+            d.y = (d.y - mean) / std
+    ctx.say("Mean = %.3f, Std = %.3f" % (float(mean), float(std)))
+    stores = [DeviceGraphStore(part, ctx.device) for part in (tr, va, te)]
+    n_train = len(tr)
+
+    model = NestedGIN_eff(None, num_layers=args.layers, use_rd=args.use_rd, RNI=args.RNI, drop_ratio=args.drop_ratio,
+                          edge_attr_dim=5, use_pos=args.use_pos, use_max_dist=args.use_max_dist)
+    if args.load_model is not None:
+        model.load_state_dict(torch.load(args.load_model, map_location="cpu"))
+    ctx.say("Using " + model.__class__.__name__ + " model")
+    model = model.to(ctx.device)
+    broadcast_parameters(model, 0)
+    optimizer = FlatAdam(model.parameters(), lr=args.lr)
+    scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=args.lr_decay_factor, patience=args.patience,
+                                  min_lr=0.00001)
+    gen = torch.Generator().manual_seed(args.seed)
+
+    def train(epoch):
+        model.train()
+        loss_all = torch.zeros((), device=ctx.device)
+        for data, n_global in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
+            optimizer.zero_grad()
+            y = data.y.view(-1, 1)
+            loss = ops.l1_loss(model(data), y)            # torch.nn.L1Loss (reference :290-291)
+            loss.backward()
+            if ctx.world > 1:
+                optimizer.all_reduce_weighted(y.size(0))
+            loss_all += loss.detach() * y.size(0)
+            optimizer.step()
+        return float(ctx.all_reduce(loss_all)) / n_train
+
+    def test(store):
+        model.eval()
+        tot = torch.zeros(2, device=ctx.device)
+        with torch.no_grad():
+            for data, _ in sharded_batches(store, args.batch_size, ctx, False):
+                y_hat = model(data)[:, 0]
+                tot[0] += torch.sum(torch.abs(y_hat - data.y.view(-1)))
+                tot[1] += y_hat.numel()
+        ctx.all_reduce(tot)
+        return float(tot[0] / tot[1]) * float(std)
+
+    if args.eval:
+        print("Test MAE: %.7f" % test(stores[2]))
+        ctx.close()
+        return
+    t1 = time.time()
+    best_val_error, count, log = None, 0, ""
+    for epoch in range(1, args.epochs + 1):
+        lr = optimizer.param_groups[0]["lr"]
+        loss = train(epoch)
+        val_error = test(stores[1])
+        scheduler.step(val_error)
+        count += 1
+        if best_val_error is None:
+            best_val_error = val_error
+        if val_error <= best_val_error or count == 10:    # reference :318-321
+            count = 0
+            test_error = test(stores[2])
+            best_val_error = val_error
+            log = ("Epoch: {:03d}, LR: {:7f}, Loss: {:.7f}, Validation MAE: {:.7f}, "
+                   "Test MAE: {:.7f}, Test MAE norm: {:.7f}").format(epoch, lr, loss, val_error, test_error,
+                                                                     test_error / float(std))
+            if ctx.rank == 0:
+                print("\n" + log + "\n")
+                with open(os.path.join(args.res_dir, "log.txt"), "a") as fh:
+                    fh.write(log + "\n")
+    if ctx.rank == 0:
+        torch.save(model.state_dict(), os.path.join(args.res_dir, "model_checkpoint{}.pth".format(args.epochs)))
+        print("Training time cost: {}s".format(time.time() - t1))
+        print(cmd_input[:-1])
+        print(log)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,12 @@ int esc_bn_eval_coef(const float* running_mean, const float* running_var, const 
  * graph-sharded data parallelism. */
 int esc_l1_loss(const float* pred, const float* y, int64_t M, int64_t denom, float grad_scale,
                 float* loss, float* dpred, void* stream);
+/* BCEWithLogitsLoss()(pred[labeled], y[labeled]), labeled = (y == y) — the OGB criterion with NaN
+ * targets ignored (run_ogb_mol.py:65-72).  denom <= 0: mean over the labeled entries of this call;
+ * > 0: explicit divisor (global labeled count under graph sharding).  dpred (may be NULL) receives
+ * d loss / d pred, 0 at unlabeled entries. */
+int esc_bce_logits_loss(const float* pred, const float* y, int64_t M, int64_t denom, float* loss,
+                        float* dpred, void* stream);
 /* torch.optim.Adam (no amsgrad, no weight decay) over one flat buffer, torch's operation order;
  * `step` is the 1-based step number. */
 int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

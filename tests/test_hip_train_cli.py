@@ -50,3 +50,50 @@ def test_loss_decreases():
         opt.step()
         losses.append(float(loss.detach()))
     assert sum(losses[-4:]) < 0.7 * sum(losses[:4]), losses
+
+
+def test_bce_logits_masked_matches_torch():
+    require_gpu()
+    import esc_gnn_amd as E
+    torch.manual_seed(3)
+    pred = (torch.randn(37, 5) * 3).cuda().requires_grad_(True)
+    y = (torch.rand(37, 5) > 0.5).float()
+    y[torch.rand(37, 5) < 0.3] = float("nan")
+    loss = E.ops.bce_with_logits_loss(pred, y.cuda())
+    loss.backward()
+    p64 = pred.detach().cpu().double().requires_grad_(True)
+    lab = y == y
+    ref = torch.nn.BCEWithLogitsLoss()(p64[lab], y.double()[lab])
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert torch.allclose(pred.grad.cpu().double(), p64.grad, atol=1e-7)
+
+
+def test_zinc_cli_two_epochs(tmp_path, monkeypatch, capsys):
+    require_gpu()
+    import esc_gnn_amd.run_zinc as rz
+    monkeypatch.chdir(tmp_path)
+    rz.main("--epochs 2 --synthetic_graphs 60 --batch_size 10 --layers 2 --h 2 --lr 0.005 --save_appendix _t".split())
+    out = capsys.readouterr().out
+    assert "Epoch: 001" in out and "Validation MAE" in out
+    res = os.path.join(tmp_path, "results", "zinc_NestedGIN_eff_t")
+    assert "model_checkpoint2.pth" in os.listdir(res) and "log.txt" in os.listdir(res)
+    sd = torch.load(os.path.join(res, "model_checkpoint2.pth"), map_location="cpu")
+    assert sd["node_type_embedding.weight"].shape == (100, 32) and sd["convs.0.lin.weight"].shape == (256, 288)
+
+
+def test_ogb_cli_runs_checkpoints_and_ensemble(tmp_path, monkeypatch, capsys):
+    require_gpu()
+    import esc_gnn_amd.run_ogb_mol as ro
+    monkeypatch.chdir(tmp_path)
+    base = ("--dataset ogbg-molpcba --gnn gin_eff --edge_nest True --efficient True --self_loop True --h 2 --runs 1 "
+            "--num_layer 2 --emb_dim 64 --batch_size 16 --synthetic_graphs 80 --log_steps 1 --save_appendix _t ")
+    ro.main((base + "--epochs 2 --ensemble --ensemble_lookback 1 --ensemble_interval 1").split())
+    out = capsys.readouterr().out
+    assert "Best validation score" in out and "Ensemble test score" in out and "Final Test" in out
+    res = os.path.join(tmp_path, "results", "ogbg-molpcba_t")
+    for f in ("run1_best_model.pth", "run1_model_checkpoint2.pth", "run1_optimizer_checkpoint2.pth", "log.txt"):
+        assert f in os.listdir(res), f
+    ro.main((base + "--epochs 3 --continue_from 2").split())          # resume: trains epoch 3 only
+    out = capsys.readouterr().out
+    assert "epoch 3" in out and "epoch 2," not in out
