@@ -25,6 +25,10 @@ class CollateArgs(ctypes.Structure):
                     "in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst",
                     "row_ptr", "bag_idx", "bag_val", "col_row", "col_val", "col_col")])
 
+class BnFuse(ctypes.Structure):
+    """mirror of `esc_bn_fuse` (include/escgnn_hip.h)"""
+    _fields_ = [("eps", c_float), ("momentum", c_float)] + [(n, c_void_p) for n in (
+        "mean", "invstd", "running_mean", "running_var", "gamma", "beta", "scale", "shift")]
 
 
 # name -> argtypes (every function returns int unless listed in _RET)
@@ -40,9 +44,11 @@ SIGNATURES = {
     "esc_gine_aggregate_fwd": [P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P],
     "esc_gine_aggregate_bwd": [P, I64, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P],
     "esc_reduce_sum": [P, I64, P, P],
+    "esc_reduce_sum_jobs": [P, I32, P],
     "esc_segment_pool_fwd": [P, I64, P, I64, I64, I32, P, I64, P],
     "esc_segment_pool_bwd": [P, I64, P, I64, I64, I32, P, I64, P],
     "esc_linear_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
+    "esc_linear_bn_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, POINTER(BnFuse), P],
     "esc_tune_set": [I32, I32],
     "esc_debug_gemm_occupancy": [I32],
     "esc_linear_bwd_input": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P],

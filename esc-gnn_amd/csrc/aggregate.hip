@@ -298,6 +298,23 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restric
   }
 }
 
+// several independent sums in one launch: workgroup j reduces job j exactly like reduce_sum_kernel
+struct SumJobs { esc_sum_job job[ESC_MAX_SUM_JOBS]; };
+__global__ __launch_bounds__(1024) void reduce_sum_jobs_kernel(SumJobs t) {
+  __shared__ double sh[16];
+  const esc_sum_job& q = t.job[blockIdx.x];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < q.n; i += blockDim.x) acc += (double)q.v[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+    q.out[0] = (float)s;
+  }
+}
+
 }  // namespace esc
 
 extern "C" {
@@ -379,6 +396,21 @@ int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream) {
   ESC_REQUIRE(out && (v || n == 0) && n >= 0, "esc_reduce_sum: bad argument");
   esc::launch(-1, esc::reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out);
   ESC_CHECK_LAUNCH("esc_reduce_sum");
+  return ESC_OK;
+}
+
+int esc_reduce_sum_jobs(const esc_sum_job* jobs, int count, void* stream) {
+  ESC_REQUIRE(count >= 0 && (jobs || count == 0), "esc_reduce_sum_jobs: bad argument");
+  for (int first = 0; first < count; first += ESC_MAX_SUM_JOBS) {
+    esc::SumJobs t{};
+    const int n = count - first < ESC_MAX_SUM_JOBS ? count - first : ESC_MAX_SUM_JOBS;
+    for (int j = 0; j < n; ++j) {
+      ESC_REQUIRE(jobs[first + j].out && (jobs[first + j].v || jobs[first + j].n == 0) && jobs[first + j].n >= 0, "esc_reduce_sum_jobs: bad job %d", first + j);
+      t.job[j] = jobs[first + j];
+    }
+    esc::launch(-1, esc::reduce_sum_jobs_kernel, dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, t);
+  }
+  ESC_CHECK_LAUNCH("esc_reduce_sum_jobs");
   return ESC_OK;
 }
 

@@ -66,4 +66,51 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- "last workgroup finishes the reduction" ------------------------------------------------------------------
+// A per-device pool of zeroed ticket counters (runtime.hip).  A kernel whose workgroups each publish a partial
+// result takes a ticket after an agent-scope release fence; the workgroup drawing the last ticket sees every
+// partial (acquire fence), finishes the reduction and re-zeroes the counter — this replaces a separate
+// few-hundred-thread "finalize" launch (a dependent launch costs ~4.5 us on MI355X whatever its size).
+// `tickets(n)` hands out a rotating window of n counters, so kernels in flight on different streams never share.
+unsigned* tickets(int n);
+// Measured on MI355X (cfg1 step, r01): the fused tail costs what the finalize launch did — the last workgroup pays
+// an atomic round trip, an L2 invalidate and cold reads of partials that were written through to memory:
+// 1.712 ms with it vs 1.692 ms without.  Kept as an option (esc_tune_set(8, 1)), off by default.
+bool last_block_finalize();
+void set_last_block_finalize(int on);
+
+// Partials that the last workgroup will read are written with agent-scope (write-through, `sc1`) stores: they
+// become visible device-wide when the store is acknowledged, so the publishing workgroups need NO L2 write-back /
+// invalidate (a full `__threadfence()` per workgroup — buffer_wbl2 + buffer_inv — cost the edge-row GEMMs +25 %).
+__device__ __forceinline__ void store_agent(float2* p, float2 v) {
+  const unsigned long long bits = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true in every thread of the workgroup that arrives last among the `nblocks` sharing `counter`.
+// All threads of the workgroup must call it (barriers inside); partials must have been written with store_agent.
+__device__ __forceinline__ bool grid_last_block(unsigned* counter, unsigned nblocks) {
+  __shared__ unsigned s_ticket;
+  __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): this thread's write-through stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const bool last = s_ticket == nblocks - 1;
+  if (last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines: the partials are read from memory
+    if (threadIdx.x == 0) *counter = 0;                  // ready for the next launch (kernel boundary orders it)
+  }
+  return last;
+}
+
+// Chan/Welford merge of two (count, mean, M2) partials
+__device__ __forceinline__ void chan_merge(double& n, double& mu, double& m2, double nb, double mub, double m2b) {
+  if (nb == 0.0) return;
+  const double tot = n + nb;
+  const double delta = mub - mu;
+  mu += delta * nb / tot;
+  m2 += m2b + delta * delta * n * nb / tot;
+  n = tot;
+}
+
 }  // namespace esc

@@ -74,7 +74,7 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
     y.slabs_x = a.take(esc_linear_bwd_weight_scratch(N, H, H));
     y.dcat = a.take(N * y.W); y.dAl = a.take(N * H); y.dT1 = a.take(N * H); y.dT2 = a.take(N * H);
     y.dagg = a.take(N * H); y.d_e = a.take(E * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
-    y.deps_part = a.take(N);
+    y.deps_part = a.take(N * (L > 0 ? L : 1));        // one vector per GINE layer, summed together at the end
     y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
     // one private slab region per weight gradient: their ordered reduces are deferred to ONE launch at the end
     int64_t sl = esc_linear_bwd_weight_scratch(E, H, H) + 64;                        // zlin
@@ -155,6 +155,7 @@ static Ctx side_ctx(const Ctx& c, hipStream_t side) {
   return x;
 }
 
+static int g_fuse_finalize = 1; // ... and their merge by the GEMM's last workgroup (no bn_finalize launch)
 static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's epilogue (no extra pass over Y)
 
 // Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
@@ -162,6 +163,10 @@ static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linea
                      int64_t M, float* Y, const esc_bn_t& bn, const BnWs& w) {
   const int64_t H = c.y.H, K = lin.in_dim;
   const bool fused = c.train && g_gemm_stats && H > 32 && c.jobs != nullptr;   // main chain only (col_stats is shared scratch)
+  if (fused && g_fuse_finalize && M > 1) {    // statistics AND their merge ride on the GEMM launch
+    esc_bn_fuse f{bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma, bn.beta, w.scale, w.shift};
+    return esc_linear_bn_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, c.y.col_stats, &f, c.s);
+  }
   ESC_TRY(esc_linear_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, fused ? c.y.col_stats : nullptr, c.s));
   if (fused)
     return esc_bn_stats_from_partials(c.y.col_stats, M, H, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean,
@@ -273,7 +278,8 @@ static int backward(const Ctx& c) {
     ESC_TRY(mlp_backward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
     (void)hipEventRecord(ss.join_b, ss.stream);
   }
-  // GINE layers, last to first
+  // GINE layers, last to first (the eps gradients are only needed by the optimiser: one reduce launch at the end)
+  std::vector<esc_sum_job> eps_jobs;
   for (int l = (int)L - 1; l >= 0; --l) {
     const esc_conv_t& cv = m->conv[l];
     const int64_t C = l == 0 ? y.C0 : H;
@@ -283,8 +289,8 @@ static int backward(const Ctx& c) {
                          y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C));
     float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
     ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
-                                   y.d_e, C, dx, W, 1, y.deps_part, c.s));
-    ESC_TRY(esc_reduce_sum(y.deps_part, N, cv.deps, c.s));
+                                   y.d_e, C, dx, W, 1, y.deps_part + (int64_t)l * N, c.s));
+    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
     if (g_materialise_edge_act)
       ESC_TRY(linear_backward(c, y.d_e, C, y.Zemb, H, nullptr, nullptr, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
     else
@@ -301,6 +307,7 @@ static int backward(const Ctx& c) {
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, y.bn_scratch, c.s));
   ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
                             y.bag_scratch, c.s));
+  if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
   if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_b, 0) != hipSuccess) {
     set_error("esc_engine: side-stream join failed");
@@ -331,7 +338,8 @@ int esc_engine_set_side_stream(int on) {
 }
 
 int esc_engine_set_gemm_stats(int on) {
-  g_gemm_stats = on != 0;
+  g_fuse_finalize = (on & 2) == 0;       // bit 1: keep the statistics epilogue but finalize in a separate launch
+  g_gemm_stats = (on & 1) != 0;
   return ESC_OK;
 }
 

@@ -221,6 +221,16 @@ __device__ __forceinline__ float4 frag_redmajor(const float* __restrict__ lds, i
 //   A_KC : A operand k-contiguous (rows = output rows)   else reduction-major (cols = output rows)
 //   B_KC : B operand k-contiguous (rows = output cols)   else reduction-major (cols = output cols)
 // =================================================================================================
+// BatchNorm finalize fused behind the statistics epilogue: the last row-tile workgroup of every column tile
+// (grid_last_block on tickets[bx]) merges that tile's partials and writes what bn_finalize_kernel would
+struct BnFuse {
+  unsigned* tickets;        // nullptr = off; one counter per column tile
+  int row_tiles;            // workgroups sharing a counter
+  float eps, momentum;
+  float* mean; float* invstd; float* running_mean; float* running_var;
+  const float* gamma; const float* beta; float* scale; float* shift;
+};
+
 struct GemmArgs {
   const float* A; int64_t lda;
   const float* B; int64_t ldb;
@@ -234,7 +244,72 @@ struct GemmArgs {
   int red_per_split;
   int accumulate;
   int a_vec, b_vec, c_slab; // alignment flags; c_slab: C is a [splits][rowsC][colsC] slab buffer
+  BnFuse fin;
 };
+
+// Merge the per-32-row (mean, M2) partials of columns [n0, n0+BN) — every group but possibly the last holds exactly
+// 32 rows, so the merge is division-free: with d_p = mean_p - pivot,  mean = pivot + S1/G,
+// M2 = sum M2_p + 32 (S2 - S1^2/G)  (fp64, shifted by the first group's mean: no cancellation), then one Chan merge
+// with the ragged last group.  NTHR/BN threads share a column (contiguous slot ranges, summed in fixed order).
+template <int BN, int NTHR>
+__device__ __forceinline__ void bn_finalize_cols(const GemmArgs& g, int n0, float* lds) {
+  static_assert(NTHR % BN == 0, "threads must tile the column block");
+  constexpr int TPC = NTHR / BN;
+  const int tid = threadIdx.x, cl = tid % BN, part = tid / BN;
+  const int col = n0 + cl;
+  const int M = g.rowsC, C = g.colsC;
+  const int full = M / 32;
+  double S1 = 0.0, S2 = 0.0, SM = 0.0, pivot = 0.0;
+  if (col < C && full > 0) {
+    pivot = (double)g.col_stats[col].x;
+    const int per = (full + TPC - 1) / TPC;
+    const int p0 = part * per, p1 = min(full, p0 + per);
+    // the partials were written through to memory by other workgroups: every load is a long-latency miss, so
+    // keep 16 of them in flight per thread
+    for (int p = p0; p < p1; p += 16) {
+      float2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = g.col_stats[(size_t)min(p + u, p1 - 1) * C + col];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (p + u < p1) {
+          const double d = (double)v[u].x - pivot;
+          S1 += d;
+          S2 += d * d;
+          SM += (double)v[u].y;
+        }
+      }
+    }
+  }
+  double* sh = reinterpret_cast<double*>(lds);      // [3][NTHR]; the staging buffers are dead by now
+  sh[tid] = S1; sh[NTHR + tid] = S2; sh[2 * NTHR + tid] = SM;
+  __syncthreads();
+  if (part != 0 || col >= C) return;
+#pragma unroll
+  for (int q = 1; q < TPC; ++q) { S1 += sh[q * BN + cl]; S2 += sh[NTHR + q * BN + cl]; SM += sh[2 * NTHR + q * BN + cl]; }
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  if (full > 0) {
+    n = 32.0 * full;
+    mu = pivot + S1 / full;
+    m2 = SM + 32.0 * (S2 - S1 * S1 / full);
+    if (m2 < 0.0) m2 = 0.0;
+  }
+  if (M > 32 * full) {
+    const float2 v = g.col_stats[(size_t)full * C + col];
+    chan_merge(n, mu, m2, (double)(M - 32 * full), (double)v.x, (double)v.y);
+  }
+  const BnFuse& f = g.fin;
+  const float is = (float)(1.0 / sqrt(m2 / (double)M + (double)f.eps));
+  f.mean[col] = (float)mu;
+  f.invstd[col] = is;
+  if (f.scale) {
+    const float sc = (f.gamma ? f.gamma[col] : 1.f) * is;
+    f.scale[col] = sc;
+    f.shift[col] = (f.beta ? f.beta[col] : 0.f) - (float)mu * sc;
+  }
+  if (f.running_mean) f.running_mean[col] = (1.f - f.momentum) * f.running_mean[col] + f.momentum * (float)mu;
+  if (f.running_var) f.running_var[col] = (1.f - f.momentum) * f.running_var[col] + f.momentum * (float)(m2 / (double)(M - 1));
+}
 
 template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB, int KW = 1>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restrict__ lds, int bx, int by, int bz) {
@@ -426,8 +501,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
           if (row < g.rowsC) { const float d = acc[i][j][r] + bv - mean; m2 = fmaf(d, d, m2); }
         }
         m2 += __shfl_xor(m2, 32, 64);
-        if (l < 32 && col < g.colsC && nvalid > 0)
-          g.col_stats[(size_t)(row0 / 32) * g.colsC + col] = make_float2(mean, m2);
+        if (l < 32 && col < g.colsC && nvalid > 0) {
+          float2* dst = g.col_stats + (size_t)(row0 / 32) * g.colsC + col;
+          if (g.fin.tickets != nullptr) store_agent(dst, make_float2(mean, m2));   // read by another workgroup
+          else *dst = make_float2(mean, m2);
+        }
       }
   }
   // ---- epilogue: C/D map of the 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -453,6 +531,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
   if constexpr (DB) {
     if (bx == 0 && threadIdx.x < BM && m0 + (int)threadIdx.x < g.rowsC)
       g.db_part[(size_t)split * g.rowsC + m0 + threadIdx.x] = dbsum;
+  }
+  if constexpr (KW == 1 && !DB) {
+    if (g.fin.tickets != nullptr) {      // uniform over the grid
+      if (grid_last_block(g.fin.tickets + bx, (unsigned)g.fin.row_tiles)) bn_finalize_cols<BN, NTHR>(g, n0, lds);
+    }
   }
 }
 
@@ -610,19 +693,25 @@ int esc_debug_gemm_occupancy(int tile_id) {
 }
 
 int esc_tune_set(int knob, int value) {
+  if (knob == 8) { set_last_block_finalize(value); return ESC_OK; }
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
   g_knob[knob] = value;
   return ESC_OK;
 }
 
-int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
-                   const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
-                   float* Y, int64_t ld_y, float* col_stats, void* stream) {
+#define ESC_TRY_(x) do { int rc__ = (x); if (rc__ != ESC_OK) return rc__; } while (0)
+constexpr int64_t FUSE_FINALIZE_MAX_ROWS = 4096;
+
+static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                           const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
+                           float* Y, int64_t ld_y, float* col_stats, const esc_bn_fuse* bn, void* stream) {
   ESC_REQUIRE(X && W && Y, "esc_linear_fwd: null pointer");
   ESC_REQUIRE(M >= 0 && N > 0 && K > 0 && ld_x >= K && ld_w >= K && ld_y >= N, "esc_linear_fwd: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
   ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_fwd: in_scale/in_shift must come together");
   ESC_REQUIRE(col_stats == nullptr || N > 32, "esc_linear_fwd: col_stats needs N > 32");
   ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_fwd: dimension too large");
+  ESC_REQUIRE(bn == nullptr || (col_stats && bn->mean && bn->invstd && M > 1), "esc_linear_bn_fwd: needs col_stats, mean, invstd and M > 1");
+  ESC_REQUIRE(bn == nullptr || ((bn->scale == nullptr) == (bn->shift == nullptr)), "esc_linear_bn_fwd: scale/shift must come together");
   if (M == 0) return ESC_OK;
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g{};
@@ -635,10 +724,39 @@ int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, c
   const int splits = 1;
   int id = (N <= 32) ? 2 : (M >= 8192 ? g_knob[KNOB_FWD_BIG] : g_knob[KNOB_FWD_SMALL]);
   if (col_stats && id >= 8) id = 4;          // in-workgroup split-K tiles keep partial sums per wave group
+  if (bn && (M > FUSE_FINALIZE_MAX_ROWS || !last_block_finalize())) {     // edge-sized: hundreds of partials per column — a wide finalize launch is faster
+    ESC_TRY_(linear_fwd_impl(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, nullptr, stream));
+    return esc_bn_stats_from_partials(col_stats, M, N, bn->eps, bn->momentum, bn->mean, bn->invstd, bn->running_mean,
+                                      bn->running_var, bn->gamma, bn->beta, bn->scale, bn->shift, stream);
+  }
+  if (bn) {
+    int bm, bn_cols, bk;
+    tile_dims(id, &bm, &bn_cols, &bk);
+    const int col_tiles = (int)cdiv(N, bn_cols);
+    g.fin.tickets = tickets(col_tiles);
+    ESC_REQUIRE(g.fin.tickets != nullptr, "esc_linear_bn_fwd: no ticket counters");
+    g.fin.row_tiles = (int)cdiv(M, bm);
+    g.fin.eps = bn->eps; g.fin.momentum = bn->momentum; g.fin.mean = bn->mean; g.fin.invstd = bn->invstd;
+    g.fin.running_mean = bn->running_mean; g.fin.running_var = bn->running_var; g.fin.gamma = bn->gamma;
+    g.fin.beta = bn->beta; g.fin.scale = bn->scale; g.fin.shift = bn->shift;
+  }
   if (in_scale) { ESC_TILE_DISPATCH(id, true, true, true, false) }
   else          { ESC_TILE_DISPATCH(id, true, true, false, false) }
   ESC_CHECK_LAUNCH("esc_linear_fwd");
   return ESC_OK;
+}
+
+int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                   const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
+                   float* Y, int64_t ld_y, float* col_stats, void* stream) {
+  return linear_fwd_impl(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, nullptr, stream);
+}
+
+int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                      const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
+                      float* Y, int64_t ld_y, float* col_stats, const esc_bn_fuse* bn, void* stream) {
+  ESC_REQUIRE(bn != nullptr, "esc_linear_bn_fwd: null bn");
+  return linear_fwd_impl(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, bn, stream);
 }
 
 int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel_v4(const float* __restr
 }
 
 // ACT / HAS_Y are compile-time so that every load in the row loop is unconditional (a run-time select around a
-// load makes hipcc branch and wait per element, which is what kept the scalar kernel at ~1 TB/s)
+// load makes hipcc branch and wait per element, which is what kept the scalar kernel at ~1 TB/s).
+// The four waves of a workgroup add their sums through LDS (fixed order) into ONE slot per workgroup, and the
+// workgroup that finishes last (grid_last_block) folds the slots into dgamma / dbeta / coef: no finalize launch.
 template <int ACT, bool HAS_Y>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __restrict__ X, int64_t ldx,
                                                                 const float* __restrict__ Y, int64_t ldy,
@@ -101,47 +103,78 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __r
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
-                                                                float2* __restrict__ partial) {
+                                                                float2* partial, unsigned* tickets,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float2* __restrict__ coef) {
   constexpr int relu = ACT;
-  const int c = (blockIdx.x * 64 + lane_id()) * 4;
-  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  __shared__ float4 sh[3][2][64];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int slot = blockIdx.y * 4 + wave;
   const int P = gridDim.y * 4;
-  if (c >= C) return;
-  const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
-  const float4 ga = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-  const float4 be = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool active = c < C;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (active) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 ga = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 be = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-  for (int r = slot; r < M; r += P) {
-    float4 g = *reinterpret_cast<const float4*>(dY + (size_t)r * ldg + c);
-    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
-    const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
-    if constexpr (ACT != 0) {
-      if constexpr (HAS_Y) {
-        const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
-        g.x *= act_grad_from_out(y.x, relu); g.y *= act_grad_from_out(y.y, relu);
-        g.z *= act_grad_from_out(y.z, relu); g.w *= act_grad_from_out(y.w, relu);
-      } else {
-        g.x *= act_grad_from_pre(fmaf(xh.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(fmaf(xh.y, ga.y, be.y), relu);
-        g.z *= act_grad_from_pre(fmaf(xh.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(fmaf(xh.w, ga.w, be.w), relu);
+    for (int r = slot; r < M; r += P) {
+      float4 g = *reinterpret_cast<const float4*>(dY + (size_t)r * ldg + c);
+      const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
+      const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
+      if constexpr (ACT != 0) {
+        if constexpr (HAS_Y) {
+          const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+          g.x *= act_grad_from_out(y.x, relu); g.y *= act_grad_from_out(y.y, relu);
+          g.z *= act_grad_from_out(y.z, relu); g.w *= act_grad_from_out(y.w, relu);
+        } else {
+          g.x *= act_grad_from_pre(fmaf(xh.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(fmaf(xh.y, ga.y, be.y), relu);
+          g.z *= act_grad_from_pre(fmaf(xh.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(fmaf(xh.w, ga.w, be.w), relu);
+        }
       }
+      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+      s2.x = fmaf(g.x, xh.x, s2.x); s2.y = fmaf(g.y, xh.y, s2.y); s2.z = fmaf(g.z, xh.z, s2.z); s2.w = fmaf(g.w, xh.w, s2.w);
     }
-    s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-    s2.x = fmaf(g.x, xh.x, s2.x); s2.y = fmaf(g.y, xh.y, s2.y); s2.z = fmaf(g.z, xh.z, s2.z); s2.w = fmaf(g.w, xh.w, s2.w);
   }
-  float2* dst = partial + (size_t)slot * C + c;
-  *reinterpret_cast<float4*>(dst) = make_float4(s1.x, s2.x, s1.y, s2.y);
-  *reinterpret_cast<float4*>(dst + 2) = make_float4(s1.z, s2.z, s1.w, s2.w);
-}
-
-// Chan/Welford merge of two (count, mean, M2) partials
-__device__ __forceinline__ void chan_merge(double& n, double& mu, double& m2, double nb, double mub, double m2b) {
-  if (nb == 0.0) return;
-  const double tot = n + nb;
-  const double delta = mub - mu;
-  mu += delta * nb / tot;
-  m2 += m2b + delta * delta * n * nb / tot;
-  n = tot;
+  if (wave > 0) { sh[wave - 1][0][lane] = s1; sh[wave - 1][1][lane] = s2; }
+  __syncthreads();
+  if (wave == 0 && active) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float4 a = sh[w][0][lane], b = sh[w][1][lane];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    float2* dst = partial + (size_t)blockIdx.y * C + c;
+    if (tickets != nullptr) {
+      store_agent(dst, make_float2(s1.x, s2.x));
+      store_agent(dst + 1, make_float2(s1.y, s2.y));
+      store_agent(dst + 2, make_float2(s1.z, s2.z));
+      store_agent(dst + 3, make_float2(s1.w, s2.w));
+    } else {
+      *reinterpret_cast<float4*>(dst) = make_float4(s1.x, s2.x, s1.y, s2.y);
+      *reinterpret_cast<float4*>(dst + 2) = make_float4(s1.z, s2.z, s1.w, s2.w);
+    }
+  }
+  if (tickets == nullptr) return;          // large M: a wide finalize launch follows
+  if (!grid_last_block(tickets + blockIdx.x, gridDim.y)) return;
+  const int col = blockIdx.x * 256 + threadIdx.x;      // the last workgroup: one thread per column, slots in order
+  if (col >= C) return;
+  double t1 = 0.0, t2 = 0.0;
+  const int P1 = (int)gridDim.y;
+  for (int p = 0; p < P1; p += 16) {       // written through to memory by other workgroups: 16 misses in flight
+    float2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)min(p + u, P1 - 1) * C + col];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (p + u < P1) { t1 += (double)v[u].x; t2 += (double)v[u].y; }
+    }
+  }
+  if (dgamma) dgamma[col] = (float)t2;
+  if (dbeta) dbeta[col] = (float)t1;
+  coef[col] = make_float2((float)(t1 / M), (float)(t2 / M));
 }
 
 // one wave per column: lanes own slots lane, lane+64, ... then a shuffle-tree merge (fixed order)
@@ -455,20 +488,31 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   const bool wide = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (!Y || ld_y % 4 == 0) && aligned16(X) &&
                     aligned16(dY) && (!Y || aligned16(Y)) && aligned16(mean) && aligned16(invstd) &&
                     (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && aligned16(scratch);
-  const int rb = rowblocks(M, wide);
+  // node-sized inputs: few fat workgroups (>= 32 rows each) whose last one folds the <= 64 slots itself;
+  // edge-sized: many workgroups + a wide finalize launch (one workgroup cannot pull hundreds of slots quickly)
+  const bool fuse = wide && M <= 4096 && last_block_finalize();
+  const int rb = fuse ? (int)(cdiv(M, 32) < 64 ? cdiv(M, 32) : 64) : rowblocks(M, wide);
   float2* partial = (float2*)scratch;
   float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
   if (wide) {
     const dim3 grid((unsigned)cdiv(C, 256), rb);
-#define ESC_BWD_PARTIAL(A, H) esc::launch(ESC_K_NORM, bn_bwd_partial_kernel_v4<A, H>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial)
+    unsigned* tk = fuse ? tickets((int)grid.x) : nullptr;
+    ESC_REQUIRE(!fuse || tk != nullptr, "esc_bn_bwd: no ticket counters");
+#define ESC_BWD_PARTIAL(A, H) esc::launch(ESC_K_NORM, bn_bwd_partial_kernel_v4<A, H>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial, tk, dgamma, dbeta, coef)
     if (relu == 0)      ESC_BWD_PARTIAL(0, false);
     else if (relu == 1) { if (Y) ESC_BWD_PARTIAL(1, true); else ESC_BWD_PARTIAL(1, false); }
     else                { if (Y) ESC_BWD_PARTIAL(2, true); else ESC_BWD_PARTIAL(2, false); }
 #undef ESC_BWD_PARTIAL
+    if (!fuse) {
+      ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
+      esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb, dgamma, dbeta, coef);
+    }
   }
-  else      esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, gamma, beta, partial);
-  ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
-  esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
+  else {
+    esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, gamma, beta, partial);
+    ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
+    esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
+  }
   ESC_CHECK_LAUNCH("esc_bn_bwd.finalize");
   const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) && (!Y || ld_y % 4 == 0) &&
                    aligned16(X) && aligned16(dY) && aligned16(dX) && (!Y || aligned16(Y)) &&

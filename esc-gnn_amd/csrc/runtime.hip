@@ -39,6 +39,32 @@ bool prof_slot(int k, hipEvent_t* start, hipEvent_t* stop) {
   return true;
 }
 
+// ticket counters for grid_last_block (common.h): one zeroed pool per device, handed out as rotating windows
+constexpr int TICKET_POOL = 4096;
+static unsigned* g_tickets[64] = {};
+static int g_ticket_pos[64] = {};
+static std::mutex g_ticket_mu;
+
+static int g_last_block = 0;
+bool last_block_finalize() { return g_last_block != 0; }
+void set_last_block_finalize(int on) { g_last_block = on != 0; }
+
+unsigned* tickets(int n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || n <= 0 || n > TICKET_POOL) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ticket_mu);
+  if (g_tickets[dev] == nullptr) {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned) * TICKET_POOL) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(unsigned) * TICKET_POOL) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_tickets[dev] = p;
+  }
+  if (g_ticket_pos[dev] + n > TICKET_POOL) g_ticket_pos[dev] = 0;
+  unsigned* out = g_tickets[dev] + g_ticket_pos[dev];
+  g_ticket_pos[dev] += n;
+  return out;
+}
+
 }  // namespace esc
 
 extern "C" {

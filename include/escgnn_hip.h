@@ -81,6 +81,11 @@ int esc_segment_pool_bwd(const float* g, int64_t ld_g, const int32_t* seg_ptr, i
 
 /* deterministic sum of n floats (fp64 accumulation) -> out[0]; finishes deps from deps_part. */
 int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream);
+/* the same sum for up to many independent vectors in one launch per ESC_MAX_SUM_JOBS jobs (the eps gradients of
+ * all GINE layers at the end of a backward pass). */
+typedef struct esc_sum_job { const float* v; int64_t n; float* out; } esc_sum_job;
+#define ESC_MAX_SUM_JOBS 16
+int esc_reduce_sum_jobs(const esc_sum_job* jobs, int count, void* stream);
 
 /* ---- a-7/a-8/a-9/a-10 dense layers on the matrix cores (exact-fp32 MFMA) -----------------
  * torch.nn.Linear call sites run_graphcount.py:54-121,183-189 (+ GINEConv.lin).
@@ -92,11 +97,32 @@ int esc_reduce_sum(const float* v, int64_t n, float* out, void* stream);
 int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
                    const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                    float* Y, int64_t ld_y, float* col_stats, void* stream);
+/* Linear followed by training-mode BatchNorm statistics: the GEMM epilogue writes the col_stats partials, which are
+ * merged — by a finalize launch, or with esc_tune_set(8, 1) and M <= 4096 by the last row-tile workgroup of every
+ * column tile of the GEMM itself — into mean / invstd (saved for the backward), the running statistics (momentum update, unbiased variance) and, when
+ * scale/shift are given, the consumer-side coefficients act(y) = relu(y*scale + shift).  Same results as
+ * esc_linear_fwd + esc_bn_stats_from_partials up to fp64 rounding of the merge.  Needs N > 32 and M > 1. */
+typedef struct esc_bn_fuse {
+  float eps, momentum;
+  float* mean;               /* [N] out */
+  float* invstd;             /* [N] out */
+  float* running_mean;       /* [N] in/out, may be NULL */
+  float* running_var;        /* [N] in/out, may be NULL */
+  const float* gamma;        /* [N] or NULL (= 1) */
+  const float* beta;         /* [N] or NULL (= 0) */
+  float* scale;              /* [N] out, may be NULL (together with shift) */
+  float* shift;
+} esc_bn_fuse;
+int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                      const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
+                      float* Y, int64_t ld_y, float* col_stats, const esc_bn_fuse* bn, void* stream);
 /* tile-shape / split knobs of the three GEMM forms (benchmark sweeps; defaults are the tuned ones):
  * 0 fwd tile for M>=8192, 1 fwd tile for small M, 2/3 same for dX, 4 dW tile, 5 dW target workgroups,
  * 6 dW minimum reduction rows per split (>=128), 7 node-sized fused-backward tile (0: 64x64xBK64, 1: 32x64xBK32 2-wave).
  * tile ids: 0 128x128xBK32, 1 64x64xBK32, 2 128x32xBK32, 3 128x64xBK32, 4 64x64xBK64, 5 32x64xBK32 (2 waves),
- * 6 32x32xBK32 (1 wave), 7 64x32xBK32 (2 waves). */
+ * 6 32x32xBK32 (1 wave), 7 64x32xBK32 (2 waves).
+ * knob 8 (default 0): 1 = node-sized BatchNorm reductions (esc_linear_bn_fwd, esc_bn_bwd) are finished by the last
+ * workgroup of the producing launch instead of a finalize launch (measured 1 % slower on the cfg1 step). */
 int esc_tune_set(int knob, int value);
 int esc_debug_gemm_occupancy(int tile_id);   /* resident workgroups/CU the runtime predicts (diagnostics) */
 /* dX[M,K] = dY[M,N] * W[N,K]  (accumulate!=0: dX += ...) */
@@ -216,7 +242,8 @@ int esc_engine_set_side_stream(int on);
 /* 1 (default): write relu(BN(.)) of the two EDGE-sized z_embedding activations once instead of re-applying the
  * affine+ReLU prologue in every consumer GEMM; 0: fully fused (less memory, slower on MI355X r01). */
 int esc_engine_set_materialise_edge_act(int on);
-/* 1 (default): BatchNorm statistics come from the producing GEMM's epilogue (col_stats) instead of a pass over Y */
+/* 1 (default): BatchNorm statistics come from the producing GEMM's epilogue (col_stats) and are merged by that
+ * launch's last workgroups (esc_linear_bn_fwd); 3: same epilogue, separate finalize launch; 0: a pass over Y */
 int esc_engine_set_gemm_stats(int on);
 int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z);
 /* loss[0] = sum|pred-y| / loss_denom (loss_denom <= 0: N).  pred (may be NULL): float[N]. */

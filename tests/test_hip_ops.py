@@ -252,3 +252,83 @@ def test_gineplus_against_message_passing_loop(E):
     o2 = naive(xs[0].to(dev), mh.to(dev), dist.to(dev), ea.to(dev))
     r2 = ref([xs[0].double()] * k, eps0.double(), lin.weight.double(), lin.bias.double())
     _chk(o2, r2, "NAIVEGINEPLUS forward")
+
+
+@pytest.mark.parametrize("M,N,K", [(15200, 256, 256), (2400, 256, 256), (2401, 256, 1280), (333, 256, 10), (50, 300, 64),
+                                   (33, 64, 16), (31, 40, 8)])
+@pytest.mark.parametrize("last_block", [0, 1])
+def test_linear_with_fused_batchnorm_statistics(E, M, N, K, last_block):
+    """esc_linear_bn_fwd: GEMM + statistics epilogue + merge (finalize launch, or knob 8: by the last workgroups of
+    the GEMM), against fp64 BatchNorm."""
+    import ctypes
+    nv = E._native
+    nv.call("esc_tune_set", 8, last_block)
+    torch.manual_seed(M + N)
+    dev = torch.device("cuda:0")
+    x, w, bias = torch.randn(M, K) * 2 + 1, torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    gamma, beta = torch.rand(N) + 0.5, torch.randn(N)
+    rm0, rv0 = torch.randn(N), torch.rand(N) + 0.5
+    xd, wd, bd, gd, btd, rmd, rvd = (t.to(dev).contiguous() for t in (x, w, bias, gamma, beta, rm0, rv0))
+    y = torch.empty(M, N, device=dev)
+    stats = torch.zeros(((M + 31) // 32) * N * 2, device=dev)
+    mean, invstd, scale, shift = (torch.empty(N, device=dev) for _ in range(4))
+    for rep in range(3):                                   # the ticket counters must be reusable launch after launch
+        f = nv.BnFuse(1e-5, 0.1, nv.ptr(mean), nv.ptr(invstd), nv.ptr(rmd) if rep == 0 else None,
+                      nv.ptr(rvd) if rep == 0 else None, nv.ptr(gd), nv.ptr(btd), nv.ptr(scale), nv.ptr(shift))
+        mean.fill_(float("nan"))
+        nv.call("esc_linear_bn_fwd", nv.ptr(xd), K, nv.ptr(wd), K, nv.ptr(bd), None, None, M, N, K, nv.ptr(y), N,
+                nv.ptr(stats), ctypes.byref(f), nv.stream())
+        r = x.double() @ w.double().t() + bias.double()
+        mu, var = r.mean(0), r.var(0, unbiased=False)
+        _chk(y, r, "y")
+        _chk(mean, mu, "mean")
+        _chk(invstd, 1 / torch.sqrt(var + 1e-5), "invstd")
+        sc = gamma.double() / torch.sqrt(var + 1e-5)
+        _chk(scale, sc, "scale")
+        _chk(shift, beta.double() - mu * sc, "shift")
+    nv.call("esc_tune_set", 8, 0)
+    _chk(rmd, 0.9 * rm0.double() + 0.1 * mu, "running_mean")
+    _chk(rvd, 0.9 * rv0.double() + 0.1 * r.var(0, unbiased=True), "running_var")
+
+
+@pytest.mark.parametrize("M,C", [(2400, 256), (50, 300), (4096, 64)])
+def test_batchnorm_backward_with_last_block_finalize(E, M, C):
+    """knob 8: the BatchNorm-backward column sums are folded by the last workgroup of the partial kernel."""
+    nv = E._native
+    torch.manual_seed(M + C)
+    dev = torch.device("cuda:0")
+    x = torch.randn(M, C) * 2 - 1
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    g = torch.randn(M, C)
+    res = []
+    for knob in (0, 1, 1):
+        nv.call("esc_tune_set", 8, knob)
+        xd, gd, bd = (t.to(dev).requires_grad_(True) for t in (x, gamma, beta))
+        y = E.ops.batch_norm_act(xd, gd, bd, torch.zeros(C, device=dev), torch.ones(C, device=dev), 1e-5, 0.1, True)
+        y.backward(g.to(dev))
+        res.append((xd.grad.cpu(), gd.grad.cpu(), bd.grad.cpu()))
+    nv.call("esc_tune_set", 8, 0)
+    x64, g64, b64 = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    r = torch.nn.functional.batch_norm(x64, None, None, g64, b64, True, 0.1, 1e-5).relu()
+    r.backward(g.double())
+    for dx, dg, db in res:
+        _chk(dx, x64.grad, "dx")
+        _chk(dg, g64.grad, "dgamma")
+        _chk(db, b64.grad, "dbeta")
+
+
+def test_reduce_sum_jobs(E):
+    import ctypes
+    nv = E._native
+
+    class Job(ctypes.Structure):
+        _fields_ = [("v", ctypes.c_void_p), ("n", ctypes.c_int64), ("out", ctypes.c_void_p)]
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    vecs = [torch.randn(n, device=dev) for n in (2400, 1, 0, 70000) + tuple(range(5, 22))]
+    outs = torch.full((len(vecs),), float("nan"), device=dev)
+    jobs = (Job * len(vecs))(*[Job(v.data_ptr() if v.numel() else None, v.numel(), outs[i:].data_ptr())
+                               for i, v in enumerate(vecs)])
+    nv.call("esc_reduce_sum_jobs", ctypes.cast(jobs, ctypes.c_void_p), len(vecs), nv.stream())
+    want = torch.tensor([float(v.double().sum()) for v in vecs])
+    assert torch.allclose(outs.cpu().double(), want.double(), rtol=1e-6, atol=1e-6)
