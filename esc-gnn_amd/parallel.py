@@ -29,32 +29,35 @@ class FlatBucket(object):
     """Re-homes parameters and gradients of a model as views into two flat fp32 buffers
     (+1 trailing slot in the gradient buffer for the node-count piggyback)."""
 
+    ALIGN = 16      # floats: every parameter (and its gradient) starts on a 64-byte boundary, so the kernels'
+                    # float4 paths apply to all of them (1-element tensors such as GINEConv.eps would otherwise
+                    # push everything behind them off 16-byte alignment)
+
     def __init__(self, params):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("FlatBucket: no parameters")
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += -(-p.numel() // self.ALIGN) * self.ALIGN
         self.numel = n
-        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)     # padding stays 0 (zero grad => no update)
         self._grad_store = torch.zeros(n + 1, dtype=torch.float32, device=dev)
         self.flat_grad = self._grad_store[:n]
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat_param[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + k].view(p.shape)
             p.grad = self.flat_grad[off:off + k].view(p.shape)
-            off += k
 
     def zero_grad(self, set_to_none=False):
         self._grad_store.zero_()
-        off = 0
-        for p in self.params:                     # autograd may have replaced .grad: re-bind the views
+        for p, off in zip(self.params, self.offsets):      # autograd may have replaced .grad: re-bind the views
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_grad[off:off + k].data_ptr():
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
-            off += k
 
     def all_reduce_weighted(self, n_local, group=None):
         """grad <- sum_r n_r * grad_r / sum_r n_r   with one SUM all-reduce."""

@@ -155,14 +155,18 @@ def test_l1_loss_and_adam(E):
     ref = torch.nn.Parameter(w.clone())
     opt = torch.optim.Adam([ref], lr=1e-2)
     mine = torch.nn.Parameter(w.clone().to(dev))
-    fopt = FlatAdam([mine], lr=1e-2)
+    one = torch.nn.Parameter(torch.ones(1, device=dev))                 # a 1-element parameter (like GINEConv.eps) in front
+    fopt = FlatAdam([one, mine], lr=1e-2)
+    assert mine.data_ptr() % 64 == 0 and mine.grad.data_ptr() % 64 == 0   # every parameter starts 64-byte aligned
     for i in range(3):
         g = torch.randn(1000)
         ref.grad = g.clone()
         opt.step()
-        fopt.flat_grad.copy_(g.to(dev))
+        fopt.zero_grad()
+        mine.grad.copy_(g.to(dev))
         fopt.step()
-    assert torch.allclose(fopt.params[0].detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(mine.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+    assert float(one.detach()) == 1.0 and float(fopt.flat_param.abs().sum()) == float(mine.detach().abs().sum()) + 1.0
 
 
 def test_bad_arguments_raise(E):

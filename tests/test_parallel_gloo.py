@@ -53,7 +53,12 @@ def _worker(rank, world, port, q):
     pred = m(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
     torch.nn.functional.l1_loss(pred, b["y"].view(-1, 1)).backward()
     total = bucket.all_reduce_weighted(b["x"].size(0))
-    q.put((rank, bucket.flat_grad.detach().numpy().copy(), float(total), bucket.flat_param.detach().numpy().copy()))
+    # parameters / gradients are views into the (64-byte aligned, padded) flat buffers: compare them unpadded
+    grads = torch.cat([p.grad.reshape(-1) for p in bucket.params])
+    params = torch.cat([p.data.reshape(-1) for p in bucket.params])
+    assert all(p.grad.data_ptr() == bucket.flat_grad[o:].data_ptr() and o % bucket.ALIGN == 0
+               for p, o in zip(bucket.params, bucket.offsets))
+    q.put((rank, grads.detach().numpy().copy(), float(total), params.detach().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 

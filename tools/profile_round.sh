@@ -12,13 +12,13 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 STEPS="--steps 30 --warmup 5"
 
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 bench.py $STEPS > "$OUT/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 bench.py $STEPS > "$OUT/bench_under_rocprof.log" 2>&1
 cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
 echo "[profile] kernel trace done"
 
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o f -- python3 bench.py --steps 5 --warmup 2 --cpu_seconds 0 --no_breakdown > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- python3 bench.py --steps 5 --warmup 2 --cpu_seconds 0 --no_breakdown > "$OUT/pmc_fetch.log" 2>&1
 echo "[profile] FETCH_SIZE pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o w -- python3 bench.py --steps 5 --warmup 2 --cpu_seconds 0 --no_breakdown > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- python3 bench.py --steps 5 --warmup 2 --cpu_seconds 0 --no_breakdown > "$OUT/pmc_write.log" 2>&1
 echo "[profile] WRITE_SIZE pass done"
 F=$(find "$OUT/pmc_fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/pmc_write" -name '*counter_collection.csv' | head -1)
