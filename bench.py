@@ -105,8 +105,22 @@ def main():
 
     stats = dict(graphs=0, nodes=0, edges=0, nnz=0)
 
+    def tally(b):
+        stats["graphs"] += args.batch_size
+        stats["nodes"] += b.x.size(0)
+        stats["edges"] += b.edge_index.size(1)
+        stats["nnz"] += b.pos_enc.numel()
+
     def step(i, count=False):
         b = store.collate(batch_ids[i % nb])
+        if engine is not None and world > 1:
+            # gradients of sum|err| (not the local mean): ONE RCCL all-reduce of grad ++ [n_local] gives the global
+            # sums, and the division by the global node count rides on the Adam launch
+            loss = engine.train_step(b, loss_denom=1)
+            opt.step(grad_denom=opt.all_reduce_sum(b.x.size(0)))
+            if count:
+                tally(b)
+            return loss
         if engine is not None:
             loss = engine.train_step(b)                     # forward + L1 + backward, gradients overwritten
         else:
@@ -114,14 +128,11 @@ def main():
             pred = model(b)
             loss = E.ops.l1_loss(pred, b.y)
             loss.backward()
-        if world > 1:                                       # ONE RCCL all-reduce: grad*n_local ++ [n_local]
-            opt.all_reduce_weighted(b.x.size(0))
+            if world > 1:                                   # ONE all-reduce: grad*n_local ++ [n_local]
+                opt.all_reduce_weighted(b.x.size(0))
         opt.step()
         if count:
-            stats["graphs"] += args.batch_size
-            stats["nodes"] += b.x.size(0)
-            stats["edges"] += b.edge_index.size(1)
-            stats["nnz"] += b.pos_enc.numel()
+            tally(b)
         return loss
 
     for i in range(args.warmup):

@@ -73,6 +73,7 @@ SIGNATURES = {
     "esc_l1_loss": [P, P, I64, I64, F32, P, P, P],
     "esc_bce_logits_loss": [P, P, I64, I64, P, P, P],
     "esc_adam_step": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P],
+    "esc_adam_step_scaled": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P, P],
     "esc_collate_cols": [P, I64, P, I64, P, P, P, P],
     "esc_collate_fill": [POINTER(CollateArgs), P],
     "esc_features_scratch_bytes": [I64, I64, I64],

@@ -66,9 +66,13 @@ __global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restric
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float one_minus_b1, float b2, float one_minus_b2,
-                                                   float bc2_sqrt, float eps, float neg_step) {
+                                                   float bc2_sqrt, float eps, float neg_step,
+                                                   const float* __restrict__ grad_denom) {
+  // grad_denom (device scalar, may be null): the all-reduced bucket holds SUMS over the global batch; dividing
+  // here saves a pass over the bucket (same rounding as grad.div_(total) followed by the plain update)
+  const float den = grad_denom ? grad_denom[0] : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = grad_denom ? g[i] / den : g[i];
     const float mi = m[i] + one_minus_b1 * (gi - m[i]);
     const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
     m[i] = mi;
@@ -104,6 +108,12 @@ int esc_bce_logits_loss(const float* pred, const float* y, int64_t M, int64_t de
 
 int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
+  return esc_adam_step_scaled(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, nullptr, stream);
+}
+
+int esc_adam_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         double lr, double beta1, double beta2, double eps, int64_t step,
+                         const float* grad_denom, void* stream) {
   ESC_REQUIRE(param && grad && exp_avg && exp_avg_sq, "esc_adam_step: null pointer");
   ESC_REQUIRE(n >= 0 && step >= 1, "esc_adam_step: bad n/step");
   if (n == 0) return ESC_OK;
@@ -112,7 +122,7 @@ int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   const unsigned blocks = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
   esc::launch(-1, adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                      (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
-                     (float)(-lr / bc1));
+                     (float)(-lr / bc1), grad_denom);
   ESC_CHECK_LAUNCH("esc_adam_step");
   return ESC_OK;
 }

@@ -20,12 +20,14 @@ class FlatAdam(FlatBucket):
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, params=self.params)]
         self.step_count = 0
 
-    def step(self):
+    def step(self, grad_denom=None):
+        """One Adam update.  grad_denom: device scalar the gradients are divided by inside the launch (the global
+        target count returned by `all_reduce_sum`)."""
         g = self.param_groups[0]
         self.step_count += 1
-        nv.call("esc_adam_step", nv.ptr(self.flat_param), nv.ptr(self.flat_grad), nv.ptr(self.exp_avg),
+        nv.call("esc_adam_step_scaled", nv.ptr(self.flat_param), nv.ptr(self.flat_grad), nv.ptr(self.exp_avg),
                 nv.ptr(self.exp_avg_sq), self.flat_param.numel(), float(g["lr"]), float(g["betas"][0]),
-                float(g["betas"][1]), float(g["eps"]), self.step_count, nv.stream())
+                float(g["betas"][1]), float(g["eps"]), self.step_count, nv.ptr(grad_denom), nv.stream())
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,

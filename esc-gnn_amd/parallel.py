@@ -70,6 +70,15 @@ class FlatBucket(object):
         self.flat_grad.div_(total)
         return total
 
+    def all_reduce_sum(self, n_local, group=None):
+        """For gradients that are already SUMS over the local targets (StepEngine.train_step(loss_denom=1)): one SUM
+        all-reduce of `grad ++ [n_local]`; returns the device scalar holding the global count, to be handed to
+        FlatAdam.step(grad_denom=...) — no scaling pass over the bucket before or after the collective."""
+        self._grad_store[-1:].fill_(float(n_local))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self._grad_store, op=dist.ReduceOp.SUM, group=group)
+        return self._grad_store[-1:]
+
 
 def broadcast_parameters(model, src=0, group=None):
     """Identical replicas at start (parameters and BN buffers)."""

@@ -242,11 +242,13 @@ def main(argv=None):
         model.train()
         loss_all = torch.zeros((), device=device)
         for data in batches(stores[0], True):
-            loss = engine.train_step(data)                # forward + L1Loss + backward (reference :494-503)
-            if world > 1:
-                optimizer.all_reduce_weighted(data.y.size(0))
-            loss_all += loss * data.y.size(0)
-            optimizer.step()
+            n_local = data.y.size(0)
+            if world > 1:     # sum-gradients, one all-reduce of grad ++ [n_local], division inside the Adam launch
+                loss_all += engine.train_step(data, loss_denom=1)
+                optimizer.step(grad_denom=optimizer.all_reduce_sum(n_local))
+            else:
+                loss_all += engine.train_step(data) * n_local   # forward + L1Loss + backward (reference :494-503)
+                optimizer.step()
         if world > 1:
             dist.all_reduce(loss_all)
         return float(loss_all) / n_train_targets

@@ -210,6 +210,11 @@ int esc_bce_logits_loss(const float* pred, const float* y, int64_t M, int64_t de
  * `step` is the 1-based step number. */
 int esc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+/* the same update on grad[i] / grad_denom[0] (device scalar): the data-parallel gradient bucket is all-reduced
+ * as SUMS over the global batch together with the global target count, and the division rides on this launch. */
+int esc_adam_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         double lr, double beta1, double beta2, double eps, int64_t step,
+                         const float* grad_denom, void* stream);
 
 /* ---- whole-step engine: NestedGIN_eff forward + L1 + backward in ONE host call ---------------------
  * (run_graphcount.py:134-194 forward, :500-503 loss/backward).  The host passes pointer tables of the

@@ -167,6 +167,17 @@ def test_l1_loss_and_adam(E):
         fopt.step()
     assert torch.allclose(mine.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
     assert float(one.detach()) == 1.0 and float(fopt.flat_param.abs().sum()) == float(mine.detach().abs().sum()) + 1.0
+    # scaled form: grad / denom inside the launch == dividing first
+    a, b2 = torch.nn.Parameter(w.clone().to(dev)), torch.nn.Parameter(w.clone().to(dev))
+    oa, ob = FlatAdam([a], lr=1e-2), FlatAdam([b2], lr=1e-2)
+    den = torch.tensor([2400.0], device=dev)
+    for i in range(3):
+        g = (torch.randn(1000) * 100).to(dev)
+        oa.zero_grad(); ob.zero_grad()
+        a.grad.copy_(g); b2.grad.copy_(g / den)
+        oa.step(grad_denom=den)
+        ob.step()
+    assert torch.equal(a.detach(), b2.detach())
 
 
 def test_bad_arguments_raise(E):

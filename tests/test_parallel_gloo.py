@@ -35,7 +35,7 @@ def _model():
     return rm.NestedGINEffRef(2, 8)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="weighted"):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,8 +51,13 @@ def _worker(rank, world, port, q):
     b = _shards(world)[rank]
     bucket.zero_grad()
     pred = m(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
-    torch.nn.functional.l1_loss(pred, b["y"].view(-1, 1)).backward()
-    total = bucket.all_reduce_weighted(b["x"].size(0))
+    if mode == "weighted":                         # local-mean gradients, scaled around the collective
+        torch.nn.functional.l1_loss(pred, b["y"].view(-1, 1)).backward()
+        total = bucket.all_reduce_weighted(b["x"].size(0))
+    else:                                          # sum-gradients; the division belongs to the optimiser launch
+        (pred - b["y"].view(-1, 1)).abs().sum().backward()
+        total = bucket.all_reduce_sum(b["x"].size(0))
+        bucket.flat_grad.div_(total)               # what esc_adam_step_scaled does per element
     # parameters / gradients are views into the (64-byte aligned, padded) flat buffers: compare them unpadded
     grads = torch.cat([p.grad.reshape(-1) for p in bucket.params])
     params = torch.cat([p.data.reshape(-1) for p in bucket.params])
@@ -63,11 +68,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_equals_sharded_objective():
-    world, port = 2, 29000 + os.getpid() % 2000
+@pytest.mark.parametrize("mode", ["weighted", "sum"])
+def test_two_rank_gradient_equals_sharded_objective(mode):
+    world, port = 2, 29000 + (os.getpid() + (7 if mode == "sum" else 0)) % 2000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
