@@ -94,7 +94,7 @@ def main():
         g.y = (g.y.view(-1) - mean) / std
     store = DeviceGraphStore(graphs, dev)
     nb = args.graphs // args.batch_size                     # full batches only, shuffle=False
-    batch_ids = [torch.arange(i * args.batch_size, (i + 1) * args.batch_size, device=dev) for i in range(nb)]
+    batch_ids = [torch.arange(i * args.batch_size, (i + 1) * args.batch_size) for i in range(nb)]   # host ids, like a sampler
 
     model = E.NestedGIN_eff(None, args.layers, args.hidden, use_rd=True, graph_pred=False, dropout=0,
                             edge_nest=True, use_cycle=True).to(dev)
@@ -112,7 +112,7 @@ def main():
         stats["nnz"] += b.pos_enc.numel()
 
     def step(i, count=False):
-        b = store.collate(batch_ids[i % nb])
+        b = store.collate(batch_ids[i % nb])                # host ids: async pinned staging, no host/device sync
         if engine is not None and world > 1:
             # gradients of sum|err| (not the local mean): ONE RCCL all-reduce of grad ++ [n_local] gives the global
             # sums, and the division by the global node count rides on the Adam launch

@@ -113,18 +113,22 @@ class DeviceGraphStore(object):
 
     def collate(self, graph_ids):
         """Batch.from_data_list over the selected graphs, on the device.  graph_ids: 1-D LongTensor/list."""
-        ids_h = torch.as_tensor(graph_ids, dtype=torch.int64).cpu() if not (torch.is_tensor(graph_ids) and graph_ids.is_cuda) else None
-        if ids_h is None:
+        # host ids are the fast path: ids and offsets travel through pinned staging buffers with async copies, so the
+        # host never waits for the device inside a training loop (device ids cost a D2H synchronisation)
+        if torch.is_tensor(graph_ids) and graph_ids.is_cuda:
             ids_d = graph_ids.to(torch.int64).contiguous()
             ids_h = ids_d.cpu()
         else:
-            ids_d = ids_h.to(self.device)
+            ids_h = torch.as_tensor(graph_ids, dtype=torch.int64).reshape(-1)
+            ids_p = torch.empty(ids_h.numel(), dtype=torch.int64, pin_memory=True)
+            ids_p.copy_(ids_h)
+            ids_d = ids_p.to(self.device, non_blocking=True)
         B = ids_h.numel()
         if B == 0:
             raise ValueError("collate: empty batch")
         if int(ids_h.min()) < 0 or int(ids_h.max()) >= self.num_graphs:
             raise IndexError("collate: graph id out of range")
-        offs = torch.zeros(4, B + 1, dtype=torch.int64)
+        offs = torch.zeros(4, B + 1, dtype=torch.int64, pin_memory=True)
         for r, p in enumerate((self.h_node_ptr, self.h_edge_ptr, self.h_nnz_ptr, self.h_y_ptr)):
             offs[r, 1:] = torch.cumsum(p[ids_h + 1] - p[ids_h], 0)
         N, E, Z, Y = (int(offs[r, B]) for r in range(4))
