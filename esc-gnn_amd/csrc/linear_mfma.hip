@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 struct ReduceJobs {
   esc_reduce_job job[ESC_MAX_REDUCE_JOBS];
   int block_start[ESC_MAX_REDUCE_JOBS + 1];
+  unsigned char vec[ESC_MAX_REDUCE_JOBS];     // 1: four consecutive gradient elements per thread (float4 slab reads)
   int count;
 };
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceJobs t) {
@@ -595,13 +596,25 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceJobs t) {
   while (j + 1 < t.count && (int)blockIdx.x >= t.block_start[j + 1]) ++j;
   const esc_reduce_job& q = t.job[j];
   const int64_t i = (int64_t)(blockIdx.x - t.block_start[j]) * blockDim.x + threadIdx.x;
-  if (i < q.n) {
-    float s = 0.f;
+  const int64_t nw = t.vec[j] ? q.n / 4 : q.n;             // work items that cover the weight gradient
+  if (i < nw) {
+    if (t.vec[j]) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-    for (int k = 0; k < q.splits; ++k) s += q.slabs[(size_t)k * q.n + i];
-    q.dw[(i / q.cols) * q.ld_dw + (i % q.cols)] = s;
-  } else if (q.db != nullptr && i - q.n < q.rows) {
-    const int64_t r = i - q.n;
+      for (int k = 0; k < q.splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(q.slabs + (size_t)k * q.n + 4 * i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int64_t e = 4 * i;
+      *reinterpret_cast<float4*>(q.dw + (e / q.cols) * q.ld_dw + (e % q.cols)) = s;
+    } else {
+      float s = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < q.splits; ++k) s += q.slabs[(size_t)k * q.n + i];
+      q.dw[(i / q.cols) * q.ld_dw + (i % q.cols)] = s;
+    }
+  } else if (q.db != nullptr && i - nw < q.rows) {
+    const int64_t r = i - nw;
     float s = 0.f;
     for (int k = 0; k < q.splits; ++k) s += q.db_part[(size_t)k * q.rows + r];
     q.db[r] = s;
@@ -905,7 +918,10 @@ int esc_slab_reduce_jobs(const esc_reduce_job* jobs, int count, void* stream) {
     ESC_REQUIRE(jobs[j].slabs && jobs[j].dw && jobs[j].n > 0 && jobs[j].splits > 0, "esc_slab_reduce_jobs: bad job %d", j);
     t.job[j] = jobs[j];
     t.block_start[j] = blocks;
-    blocks += (int)cdiv(jobs[j].n + (jobs[j].db ? jobs[j].rows : 0), 256);
+    const esc_reduce_job& q = jobs[j];
+    const bool vec = q.n % 4 == 0 && q.cols % 4 == 0 && q.ld_dw % 4 == 0 && aligned16(q.slabs) && aligned16(q.dw);
+    t.vec[j] = vec ? 1 : 0;
+    blocks += (int)cdiv((vec ? q.n / 4 : q.n) + (q.db ? q.rows : 0), 256);
   }
   t.block_start[count] = blocks;
   esc::launch(ESC_K_LINEAR, slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
