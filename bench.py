@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--lr", type=float, default=1e-2)
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no_breakdown", action="store_true")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="esc_engine_set_side_stream mode (default: the library's; 0 = everything on one stream)")
     ap.add_argument("--path", choices=("engine", "autograd"), default="engine",
                     help="engine: one esc_engine_train_step call per step; autograd: per-op torch.autograd path")
     return ap.parse_args()
@@ -80,6 +82,8 @@ def main():
     from esc_gnn_amd.datasets import build_count_dataset
     from esc_gnn_amd.store import DeviceGraphStore
 
+    if args.streams is not None:
+        nv.call("esc_engine_set_side_stream", args.streams)
     torch.manual_seed(0)
     # ---- dataset: synthetic graphs -> HIP feature build -> HBM-resident store -----------------------
     t0 = time.time()

@@ -39,11 +39,13 @@ struct Layout {
   float* e[ESC_MAX_LAYERS]; float* agg[ESC_MAX_LAYERS]; MlpWs conv[ESC_MAX_LAYERS];
   MlpWs xemb; float *cat, *Yl; BnWs bl; float *pred, *dpred;
   // backward scratch
-  float *dcat, *dAl, *dT1, *dT2, *dagg, *d_e, *dZemb, *dAz, *deps_part;
+  float *dcat, *dAl, *dT1, *dT2, *dagg, *dZemb, *dAz, *deps_part;
+  float* d_e[ESC_MAX_LAYERS];      // one per GINE layer: the edge stream consumes d_e[l] while the node chain moves on
   float *bn_scratch, *bag_scratch, *slabs;
   float *col_stats;               // GEMM-epilogue BatchNorm partials: float2[ceil(rows/32)][H]
   // private scratch of the x_embedding branch (runs on a side stream next to the z/conv chain)
   float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
+  float *bn_scratch_e, *col_stats_e;   // the edge stream's own BatchNorm scratch / GEMM-epilogue partials
   int64_t total;
 };
 
@@ -69,11 +71,14 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   y.bn_scratch = a.take(esc_bn_scratch(H));
   y.bn_scratch_x = a.take(esc_bn_scratch(H));
   y.col_stats = a.take(2 * ((E > N ? E : N) / 32 + 1) * H);
+  y.bn_scratch_e = a.take(esc_bn_scratch(H));
+  y.col_stats_e = a.take(2 * (E / 32 + 1) * H);
   if (train) {
     y.dT1x = a.take(N * H); y.dT2x = a.take(N * H);
     y.slabs_x = a.take(esc_linear_bwd_weight_scratch(N, H, H));
     y.dcat = a.take(N * y.W); y.dAl = a.take(N * H); y.dT1 = a.take(N * H); y.dT2 = a.take(N * H);
-    y.dagg = a.take(N * H); y.d_e = a.take(E * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
+    y.dagg = a.take(N * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
+    for (int l = 0; l < L; ++l) y.d_e[l] = a.take(E * (l == 0 ? C0 : H));
     y.deps_part = a.take(N * (L > 0 ? L : 1));        // one vector per GINE layer, summed together at the end
     y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
     // one private slab region per weight gradient: their ordered reduces are deferred to ONE launch at the end
@@ -134,6 +139,44 @@ struct SideStream {
 static int g_materialise_edge_act = 1;
 static int g_use_side_stream = 0;     // esc_engine_set_side_stream(); measured neutral-to-negative on MI355X r01
 
+// The edge-sized conv.lin GEMMs (e_l = lin_l(z_emb) forward; dX/dW of lin_l backward) depend on the node chain only
+// through e_l / d_e_l: they run on a second HIP stream and fill the CUs that the latency-bound node-sized launches
+// (152 workgroups on 256 CUs) leave idle.  One event per dependency, no host synchronisation.
+struct EdgeStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t z_ready = nullptr, joined = nullptr, e_ready[ESC_MAX_LAYERS] = {}, de_ready[ESC_MAX_LAYERS] = {};
+  bool ok = false;
+};
+static int g_edge_priority_low = 1;
+static int g_use_edge_stream = 1;     // esc_engine_set_side_stream() bit 1
+static EdgeStream& edge_stream() {
+  static thread_local EdgeStream es;
+  static thread_local EdgeStream off;   // ok == false
+  if (!g_use_edge_stream) return off;
+  if (!es.ok && es.stream == nullptr) {
+    // lowest priority: when workgroup slots free up, the latency-critical node chain is served first
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    bool good = hipStreamCreateWithPriority(&es.stream, hipStreamNonBlocking, g_edge_priority_low ? least : greatest) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&es.z_ready, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&es.joined, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; l < ESC_MAX_LAYERS; ++l) {
+      good = good && hipEventCreateWithFlags(&es.e_ready[l], hipEventDisableTiming) == hipSuccess;
+      good = good && hipEventCreateWithFlags(&es.de_ready[l], hipEventDisableTiming) == hipSuccess;
+    }
+    es.ok = good;
+  }
+  return es;
+}
+// `waiter` continues only after everything queued on `src` so far
+static int chain(hipEvent_t ev, hipStream_t src, hipStream_t waiter) {
+  if (hipEventRecord(ev, src) != hipSuccess || hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) {
+    set_error("esc_engine: stream event failed");
+    return ESC_ELAUNCH;
+  }
+  return ESC_OK;
+}
+
 static SideStream& side_stream() {
   static thread_local SideStream ss;
   static thread_local SideStream off;   // ok == false
@@ -145,6 +188,13 @@ static SideStream& side_stream() {
     ss.ok = good;
   }
   return ss;
+}
+static Ctx edge_ctx(const Ctx& c, hipStream_t edge) {       // same job list / slab cursor: host-side bookkeeping only
+  Ctx x = c;
+  x.s = edge;
+  x.y.bn_scratch = c.y.bn_scratch_e;
+  x.y.col_stats = c.y.col_stats_e;
+  return x;
 }
 static Ctx side_ctx(const Ctx& c, hipStream_t side) {
   Ctx x = c;
@@ -213,17 +263,32 @@ static int forward(const Ctx& c) {
   const esc_batch_t* b = c.b;
   const Layout& y = c.y;
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W;
-  // ESC bag + z_embedding (reference :155-156)
-  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, c.s));
-  ESC_TRY(bn_coeffs(c, y.Zb, H, E, m->zbn0, y.zb0));
+  // ---- edge pipeline: ESC bag, z_embedding (reference :155-156) and the edge terms e_l = lin_l(z_emb) of ALL layers
+  // (:161,:169 inside GINEConv).  It touches the node chain only through e_l, so it runs on the edge stream.
+  EdgeStream& es = edge_stream();
+  Ctx ce = c;
+  if (es.ok) {
+    ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));       // the batch arrays were produced on the caller's stream
+    ce = edge_ctx(c, es.stream);
+  }
+  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, ce.s));
+  ESC_TRY(bn_coeffs(ce, y.Zb, H, E, m->zbn0, y.zb0));
   const bool mat = g_materialise_edge_act != 0;
   if (mat) {
-    ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, c.s));
-    ESC_TRY(linear_bn(c, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
+    ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, ce.s));
+    ESC_TRY(linear_bn(ce, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
   } else {
-    ESC_TRY(linear_bn(c, y.Zb, H, m->zlin, y.zb0.scale, y.zb0.shift, E, y.Yz, m->zbn1, y.zb1));
+    ESC_TRY(linear_bn(ce, y.Zb, H, m->zlin, y.zb0.scale, y.zb0.shift, E, y.Yz, m->zbn1, y.zb1));
   }                                                                       // z_emb = relu(Yz*scale+shift)
-  if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, c.s));
+  if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, ce.s));
+  for (int l = 0; l < L; ++l) {
+    const esc_conv_t& cv = m->conv[l];
+    const int64_t C = l == 0 ? y.C0 : H;
+    if (mat) ESC_TRY(esc_linear_fwd(y.Zemb, H, cv.lin.w, H, cv.lin.b, nullptr, nullptr, E, C, H, y.e[l], C, nullptr, ce.s));
+    else     ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], C, nullptr, ce.s));
+    if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+  }
+  // ---- node pipeline
   // xs[0] = x_embedding(x) (reference :166) — side stream
   SideStream& ss = side_stream();
   if (ss.ok) {
@@ -243,8 +308,7 @@ static int forward(const Ctx& c) {
     const int64_t C = l == 0 ? y.C0 : H;
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
-    if (mat) ESC_TRY(esc_linear_fwd(y.Zemb, H, cv.lin.w, H, cv.lin.b, nullptr, nullptr, E, C, H, y.e[l], C, nullptr, c.s));
-    else     ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], C, nullptr, c.s));
+    if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
     ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W));
   }
@@ -279,6 +343,8 @@ static int backward(const Ctx& c) {
     (void)hipEventRecord(ss.join_b, ss.stream);
   }
   // GINE layers, last to first (the eps gradients are only needed by the optimiser: one reduce launch at the end)
+  EdgeStream& es = edge_stream();
+  const Ctx ce = es.ok ? edge_ctx(c, es.stream) : c;
   std::vector<esc_sum_job> eps_jobs;
   for (int l = (int)L - 1; l >= 0; --l) {
     const esc_conv_t& cv = m->conv[l];
@@ -289,24 +355,27 @@ static int backward(const Ctx& c) {
                          y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C));
     float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
     ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
-                                   y.d_e, C, dx, W, 1, y.deps_part + (int64_t)l * N, c.s));
+                                   y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
+    if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));   // lin_l backward: edge stream
     if (g_materialise_edge_act)
-      ESC_TRY(linear_backward(c, y.d_e, C, y.Zemb, H, nullptr, nullptr, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
+      ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Zemb, H, nullptr, nullptr, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
     else
-      ESC_TRY(linear_backward(c, y.d_e, C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
+      ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
   }
   if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
-  // z_embedding + bag
+  // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order); it overlaps the
+  // x_embedding backward queued above on the node stream
   const bool mat = g_materialise_edge_act != 0;
   ESC_TRY(esc_bn_bwd(y.Yz, H, mat ? y.Zemb : nullptr, H, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma,
-                     m->zbn1.beta, 1, y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, y.bn_scratch, c.s));
-  if (mat) ESC_TRY(linear_backward(c, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
-  else     ESC_TRY(linear_backward(c, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
+                     m->zbn1.beta, 1, y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, ce.y.bn_scratch, ce.s));
+  if (mat) ESC_TRY(linear_backward(ce, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
+  else     ESC_TRY(linear_backward(ce, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
   ESC_TRY(esc_bn_bwd(y.Zb, H, mat ? y.A0 : nullptr, H, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
-                     y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, y.bn_scratch, c.s));
+                     y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, ce.y.bn_scratch, ce.s));
   ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
-                            y.bag_scratch, c.s));
+                            y.bag_scratch, ce.s));
+  if (es.ok) ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));      // gradient reductions need both pipelines
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
   if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_b, 0) != hipSuccess) {
@@ -333,7 +402,9 @@ using namespace esc;
 extern "C" {
 
 int esc_engine_set_side_stream(int on) {
-  g_use_side_stream = on != 0;
+  g_use_edge_stream = (on & 2) != 0;
+  g_edge_priority_low = (on & 4) == 0;      // bit 2: give the edge stream the HIGHEST priority instead (experiments)
+  g_use_side_stream = (on & 1) != 0;
   return ESC_OK;
 }
 

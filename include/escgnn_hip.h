@@ -242,7 +242,8 @@ typedef struct esc_batch_t {
   const int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
   const int32_t *row_ptr, *bag_idx, *bag_val, *col_ptr, *col_row, *col_val, *col_col;
 } esc_batch_t;
-/* run the x_embedding branch on a second HIP stream (event fork/join); default off */
+/* bit 1 (default on): the edge-sized conv.lin GEMMs of all layers run on a second HIP stream, ordered against the
+ * node chain by one event per dependency; bit 0 (default off): the x_embedding branch on a further stream.  Default 2. */
 int esc_engine_set_side_stream(int on);
 /* 1 (default): write relu(BN(.)) of the two EDGE-sized z_embedding activations once instead of re-applying the
  * affine+ReLU prologue in every consumer GEMM; 0: fully fused (less memory, slower on MI355X r01). */
