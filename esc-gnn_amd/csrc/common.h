@@ -76,6 +76,8 @@ unsigned* tickets(int n);
 // Measured on MI355X (cfg1 step, r01): the fused tail costs what the finalize launch did — the last workgroup pays
 // an atomic round trip, an L2 invalidate and cold reads of partials that were written through to memory:
 // 1.712 ms with it vs 1.692 ms without.  Kept as an option (esc_tune_set(8, 1)), off by default.
+int norm_rowblock_cap();              // workgroups per column block of the BatchNorm reduction kernels (esc_tune_set(9, v))
+void set_norm_rowblock_cap(int v);
 bool last_block_finalize();
 void set_last_block_finalize(int on);
 

@@ -344,7 +344,10 @@ static int backward(const Ctx& c) {
   }
   // GINE layers, last to first (the eps gradients are only needed by the optimiser: one reduce launch at the end)
   EdgeStream& es = edge_stream();
-  const Ctx ce = es.ok ? edge_ctx(c, es.stream) : c;
+  Ctx ce = es.ok ? edge_ctx(c, es.stream) : c;
+  std::vector<esc_reduce_job> edge_jobs;     // the edge pipeline's weight gradients are reduced after the join,
+  edge_jobs.reserve(ESC_MAX_REDUCE_JOBS);    // the node pipeline's while the edge tail is still running
+  if (es.ok && c.jobs) ce.jobs = &edge_jobs;
   std::vector<esc_sum_job> eps_jobs;
   for (int l = (int)L - 1; l >= 0; --l) {
     const esc_conv_t& cv = m->conv[l];
@@ -375,9 +378,13 @@ static int backward(const Ctx& c) {
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, ce.y.bn_scratch, ce.s));
   ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
                             y.bag_scratch, ce.s));
-  if (es.ok) ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));      // gradient reductions need both pipelines
+  // node-side reductions first (with an edge stream they overlap its tail), then join, then the edge-side ones
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
+  if (es.ok) {
+    ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));
+    if (!edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), c.s));
+  }
   if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_b, 0) != hipSuccess) {
     set_error("esc_engine: side-stream join failed");
     return ESC_ELAUNCH;

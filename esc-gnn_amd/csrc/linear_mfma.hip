@@ -707,6 +707,7 @@ int esc_debug_gemm_occupancy(int tile_id) {
 
 int esc_tune_set(int knob, int value) {
   if (knob == 8) { set_last_block_finalize(value); return ESC_OK; }
+  if (knob == 9) { set_norm_rowblock_cap(value); return ESC_OK; }
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
   g_knob[knob] = value;
   return ESC_OK;

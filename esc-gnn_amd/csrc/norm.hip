@@ -10,7 +10,7 @@
 
 namespace esc {
 
-constexpr int NORM_ROWBLOCKS = 64;
+constexpr int NORM_ROWBLOCKS = 512;          // scratch sizing: most row blocks (= workgroups per column block) ever used
 
 // fused activation after the affine: 0 none, 1 ReLU, 2 ELU(alpha=1) (zinc_models.py:513-522 uses ELU)
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -392,8 +392,10 @@ __global__ __launch_bounds__(256) void bn_eval_coef_kernel(const float* __restri
 }
 
 // >= 4 rows per wave slot (scalar kernels keep the old 64-block cap: their finalize cost grows with the slot count)
-static inline int rowblocks(int64_t M, bool wide) {
-  const int64_t cap = wide ? NORM_ROWBLOCKS : 64;
+// forward statistics: 64 (their finalize merges 4 slots per block with Chan's formula, its cost grows with the count);
+// backward sums: norm_rowblock_cap() = 256 (one slot per block, plain sums) — swept on MI355X: 35 -> 28 us edge-sized
+static inline int rowblocks(int64_t M, bool wide, bool backward = false) {
+  const int64_t cap = (wide && backward) ? norm_rowblock_cap() : 64;
   const int64_t want = cdiv(M, 16);
   return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
@@ -491,7 +493,7 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   // node-sized inputs: few fat workgroups (>= 32 rows each) whose last one folds the <= 64 slots itself;
   // edge-sized: many workgroups + a wide finalize launch (one workgroup cannot pull hundreds of slots quickly)
   const bool fuse = wide && M <= 4096 && last_block_finalize();
-  const int rb = fuse ? (int)(cdiv(M, 32) < 64 ? cdiv(M, 32) : 64) : rowblocks(M, wide);
+  const int rb = fuse ? (int)(cdiv(M, 32) < 64 ? cdiv(M, 32) : 64) : rowblocks(M, wide, true);
   float2* partial = (float2*)scratch;
   float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
   if (wide) {

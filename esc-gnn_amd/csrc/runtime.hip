@@ -49,6 +49,10 @@ static int g_last_block = 0;
 bool last_block_finalize() { return g_last_block != 0; }
 void set_last_block_finalize(int on) { g_last_block = on != 0; }
 
+static int g_norm_rowblock_cap = 256;
+int norm_rowblock_cap() { return g_norm_rowblock_cap; }
+void set_norm_rowblock_cap(int v) { g_norm_rowblock_cap = v < 1 ? 1 : (v > 512 ? 512 : v); }
+
 unsigned* tickets(int n) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || n <= 0 || n > TICKET_POOL) return nullptr;

@@ -122,7 +122,8 @@ int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w
  * tile ids: 0 128x128xBK32, 1 64x64xBK32, 2 128x32xBK32, 3 128x64xBK32, 4 64x64xBK64, 5 32x64xBK32 (2 waves),
  * 6 32x32xBK32 (1 wave), 7 64x32xBK32 (2 waves).
  * knob 8 (default 0): 1 = node-sized BatchNorm reductions (esc_linear_bn_fwd, esc_bn_bwd) are finished by the last
- * workgroup of the producing launch instead of a finalize launch (measured 1 % slower on the cfg1 step). */
+ * workgroup of the producing launch instead of a finalize launch (measured 1 % slower on the cfg1 step).
+ * knob 9 (default 256, 1..512): workgroups per 256-column block of the BatchNorm-backward reduction kernel. */
 int esc_tune_set(int knob, int value);
 int esc_debug_gemm_occupancy(int tile_id);   /* resident workgroups/CU the runtime predicts (diagnostics) */
 /* dX[M,K] = dY[M,N] * W[N,K]  (accumulate!=0: dX += ...) */
