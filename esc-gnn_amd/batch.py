@@ -110,6 +110,11 @@ class Batch(Data):
 
     def to_data_list(self):
         """Inverse of from_data_list (reference batch.py:151-211)."""
+        lazy = getattr(self, "_lazy_slices", None)
+        if self._slices is None and lazy is not None:      # device-collated batches derive them on demand
+            slices, shifts = lazy()
+            object.__setattr__(self, "_slices", slices)
+            object.__setattr__(self, "_shifts", shifts)
         if self._slices is None:
             raise RuntimeError("Cannot reconstruct data list from batch because the batch object was "
                                "not created using Batch.from_data_list()")

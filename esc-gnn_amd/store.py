@@ -188,6 +188,17 @@ class DeviceGraphStore(object):
                          n_cols=N_COLS)
         plan._keepalive = (slab, offs_d, ids_d)
         object.__setattr__(out, "_esc_plan", plan)
+        has_attr = self.edge_attr_all is not None
+
+        def lazy_slices():            # Batch.to_data_list bookkeeping (reference batch.py:151-211), only when asked for
+            node, edge, nnz, yy = (offs[r].tolist() for r in range(4))
+            zero = [0] * B
+            slices = dict(x=node, edge_index=edge, y=yy, pos_enc=nnz, pos_index=nnz, pos_batch=nnz)
+            shifts = dict(x=zero, edge_index=node[:-1], y=zero, pos_enc=zero, pos_index=zero, pos_batch=edge[:-1])
+            if has_attr:
+                slices["edge_attr"], shifts["edge_attr"] = edge, zero
+            return slices, shifts
+        object.__setattr__(out, "_lazy_slices", lazy_slices)
         return out
 
 

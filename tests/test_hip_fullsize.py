@@ -1,0 +1,229 @@
+"""BASELINE-size parity through size-independent properties (configs[1]: h=3, bs=128, L=4, H=256 — N≈2 400 nodes,
+E≈15 200 edges, Z≈5.5·10^5 histogram entries; configs[2] shape: h=4, bs=256).  The oracle finishes the feature build
+of a whole split too slowly for a test, so at these sizes the HIP path is held to properties instead:
+
+  * feature build: a random sample of the graphs against the CPU oracle (bit-exact) + run-to-run determinism
+  * collate: round trip  to_data_list(collate(ids)) == the stored graphs,  idempotence,  CSR/CSC sortedness
+  * bag / aggregate: fp64 checksums computed from the definition by independent torch ops on the device
+  * training step: the CPU oracle model in fp64 (a few seconds at this size) for predictions, loss and every gradient;
+    engine path == autograd path (two implementations); invariance of the loss under a permutation of the graphs in
+    the batch; finite-difference check of the loss gradient along a random direction
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import require_gpu
+import ref_features as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def E():
+    require_gpu()
+    import esc_gnn_amd
+    return esc_gnn_amd
+
+
+@pytest.fixture(scope="module", params=[(3, 128), (4, 256)], ids=["cfg1_h3_bs128", "cfg3_h4_bs256"])
+def world(request, E):
+    from esc_gnn_amd.datasets import build_count_dataset
+    h, bs = request.param
+    graphs = build_count_dataset(0, 2 * bs, h=h, use_rd=True, self_loop=True)
+    y = torch.cat([g.y.view(-1) for g in graphs])
+    for g in graphs:
+        g.y = (g.y.view(-1) - y.mean()) / y.std()
+    store = E.DeviceGraphStore(graphs, DEV)
+    return dict(h=h, bs=bs, graphs=graphs, store=store)
+
+
+def test_feature_build_sample_matches_oracle_and_is_deterministic(E, world):
+    from esc_gnn_amd.datasets import synthetic_count_graphs
+    h, graphs = world["h"], world["graphs"]
+    raw = synthetic_count_graphs(0, len(graphs))
+    rng = np.random.RandomState(1)
+    for g in rng.choice(len(graphs), size=6, replace=False):
+        ei = raw[g].edge_index.numpy()
+        want = orc.encode_graph(ei[0], ei[1], raw[g].x.shape[0], h, True, True)
+        got = graphs[g]
+        assert np.array_equal(got.edge_index.numpy(), np.stack([want["edge_src"], want["edge_dst"]]))
+        for k in ("pos_enc", "pos_index", "pos_batch"):
+            assert np.array_equal(got[k].numpy(), want[k]), (g, k)
+    again = E.create_subgraphs_many(raw, h, use_rd=True, self_loop=True)
+    for a, b in zip(again, graphs):
+        for k in ("edge_index", "pos_enc", "pos_index", "pos_batch"):
+            assert torch.equal(a[k], b[k])
+
+
+def test_collate_round_trip_idempotence_sortedness(E, world):
+    store, graphs, bs = world["store"], world["graphs"], world["bs"]
+    ids = torch.randperm(len(graphs), generator=torch.Generator().manual_seed(3))[:bs]
+    b1, b2 = store.collate(ids), store.collate(ids)
+    for k in b1.keys:
+        assert torch.equal(b1[k], b2[k]), k                                  # idempotent
+    parts = b1.to_data_list()
+    assert len(parts) == bs
+    for p, g in zip(parts, ids.tolist()):
+        for k in ("x", "edge_index", "y", "pos_enc", "pos_index", "pos_batch"):
+            assert torch.equal(p[k].cpu().reshape(-1), graphs[g][k].reshape(-1).to(p[k].dtype)), (g, k)
+    plan = E.plan_of(b1)
+    for ptr, n in ((plan.in_ptr, plan.num_edges), (plan.out_ptr, plan.num_edges), (plan.row_ptr, plan.nnz),
+                   (plan.col_ptr, plan.nnz)):
+        p = ptr.cpu().long()
+        assert int(p[0]) == 0 and int(p[-1]) == n and bool((p[1:] >= p[:-1]).all())
+    dst = b1.edge_index[1][plan.in_edge.long()]
+    assert bool((dst[1:] >= dst[:-1]).all())                                 # CSR by destination, stable inside a row
+    same = dst[1:] == dst[:-1]
+    assert bool((plan.in_edge[1:][same] > plan.in_edge[:-1][same]).all())
+    cols = plan.col_col.long()
+    assert bool((cols[1:] >= cols[:-1]).all())                               # CSC of the bag sorted by histogram bin
+
+
+def test_bag_and_aggregate_checksums(E, world):
+    store, bs = world["store"], world["bs"]
+    b = store.collate(torch.arange(bs))
+    plan = E.plan_of(b)
+    torch.manual_seed(0)
+    H = 256
+    table = torch.randn(1800, H, device=DEV)
+    z = E.ops.esc_bag(table, plan)
+    # definition: z[e] = sum_k pos_enc[k] * table[pos_index[k]] over entries with pos_batch[k] == e
+    want = torch.zeros(plan.num_edges, H, dtype=torch.float64, device=DEV)
+    want.index_add_(0, b.pos_batch, table.double()[b.pos_index] * b.pos_enc.double().unsqueeze(1))
+    assert float((z.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert abs(float(z.double().sum()) - float(want.sum())) <= 1e-6 * float(want.abs().sum())
+    x = torch.randn(plan.num_nodes, H, device=DEV)
+    e = torch.randn(plan.num_edges, H, device=DEV)
+    eps = torch.tensor([0.3], device=DEV)
+    out = E.ops.gine_aggregate(x, e, eps, plan)
+    src, dst = b.edge_index
+    ref = (1.0 + 0.3) * x.double()
+    ref.index_add_(0, dst, torch.relu(x.double()[src] + e.double()))
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    # column checksums (a reduction over all rows): exact up to fp32 accumulation order
+    assert torch.allclose(out.double().sum(0), ref.sum(0), rtol=1e-6, atol=1e-3)
+
+
+def _model(E, seed=0):
+    torch.manual_seed(seed)
+    m = E.NestedGIN_eff(None, 4, 256, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to(DEV)
+    with torch.no_grad():                        # x = ones makes the x_embedding BatchNorms degenerate: perturb the input path
+        for p in m.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    return m
+
+
+def _randomise_x(batch):
+    g = torch.Generator(device=DEV).manual_seed(5)
+    batch.x = torch.randn(batch.x.shape, device=DEV, generator=g)
+    return batch
+
+
+def test_train_step_against_fp64_oracle_at_full_size(E, world):
+    """Whole training step at BASELINE size against the CPU oracle model run in fp64 (and fp32 for the error bar):
+    predictions / loss within 1e-5, every gradient as accurate as the fp32 oracle; engine == autograd path."""
+    import copy
+    import ref_model as rm
+    store, bs = world["store"], world["bs"]
+    b = _randomise_x(store.collate(torch.arange(bs)))
+    torch.manual_seed(21)
+    ref = rm.NestedGINEffRef(4, 256)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1 and "bias" not in n:
+                p.add_(0.1 * torch.randn_like(p))
+    mine = E.NestedGIN_eff(None, 4, 256, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    twin = copy.deepcopy(mine)
+    cpu = {k: b[k].cpu() for k in ("x", "edge_index", "pos_enc", "pos_index", "pos_batch", "batch", "y")}
+    ref.train()
+    pr = ref(cpu["x"], cpu["edge_index"], cpu["pos_enc"], cpu["pos_index"], cpu["pos_batch"], cpu["batch"])
+    lr = torch.nn.functional.l1_loss(pr, cpu["y"].view(-1, 1))
+    lr.backward()
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad()
+    p64 = ref64(cpu["x"].double(), cpu["edge_index"], cpu["pos_enc"], cpu["pos_index"], cpu["pos_batch"], cpu["batch"])
+    l64 = torch.nn.functional.l1_loss(p64, cpu["y"].double().view(-1, 1))
+    l64.backward()
+
+    eng = E.StepEngine(mine)
+    mine.train()
+    loss, pred = eng.train_step(b, return_pred=True)
+    scale = max(1.0, float(p64.abs().max()))
+    assert float((pred.detach().cpu().double() - p64.detach()).abs().max()) / scale <= 1e-5
+    assert abs(float(loss.detach()) - float(l64.detach())) <= 1e-5 * max(1.0, abs(float(l64.detach())))
+    # Gradients: as accurate as the fp32 oracle (error vs fp64 <= max(1e-5, 3x its error)).  At this size ~6*10^5
+    # activations pass through each ReLU, so now and then ONE pre-activation sits within fp32 rounding of zero and the two
+    # fp32 implementations pick different sides of the kink: a rank-one difference (one row's g, g*x) that is large in
+    # max-norm but negligible in Frobenius norm.  Such tensors must pass the Frobenius test, and only a few may need it.
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    kinked = []
+    for n, p in mine.named_parameters():
+        truth = g64[n].grad
+        sc = max(1.0, float(truth.abs().max()))
+        diff = p.grad.detach().cpu().double() - truth
+        e_mine = float(diff.abs().max()) / sc
+        e_ref = float((g32[n].grad.double() - truth).abs().max()) / sc
+        if e_mine <= max(1e-5, 3 * e_ref):
+            continue
+        rel_f = float(diff.norm()) / max(float(truth.norm()), 1e-12)
+        assert rel_f <= 1e-3, "grad %s: HIP error %.3g vs fp32-oracle error %.3g, relative Frobenius %.3g" % (n, e_mine, e_ref, rel_f)
+        kinked.append(n)
+    assert len(kinked) <= 4, kinked
+    # the per-op autograd path is a second implementation of the same step
+    twin.train()
+    lt = E.ops.l1_loss(twin(b), b.y)
+    lt.backward()
+    assert abs(float(lt.detach()) - float(loss.detach())) <= 1e-5 * max(1.0, abs(float(lt.detach())))
+    tw = dict(twin.named_parameters())
+    for n, p in mine.named_parameters():
+        sc = max(1.0, float(tw[n].grad.abs().max()))
+        assert float((p.grad - tw[n].grad).abs().max()) / sc <= 1e-4, n
+
+
+def test_loss_invariant_under_graph_permutation(E, world):
+    store, bs = world["store"], world["bs"]
+    eng = E.StepEngine(_model(E))
+    ids = torch.arange(bs)
+    perm = ids[torch.randperm(bs, generator=torch.Generator().manual_seed(9))]
+    l1 = float(eng.train_step(store.collate(ids)))
+    g1 = [p.grad.clone() for p in eng.model.parameters()]
+    l2 = float(eng.train_step(store.collate(perm)))
+    assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l1))
+    for (name, p), g in zip(eng.model.named_parameters(), g1):
+        if name.startswith("x_embedding"):       # dataset x = ones: zero-variance BatchNorm, gradients are rounding noise
+            continue
+        # a different row order only re-associates the fp32 sums over ~2 400 / ~15 200 rows
+        # (biases in front of a BatchNorm have a mathematically zero gradient: absolute floor)
+        assert float((p.grad - g).norm()) <= 1e-3 * float(g.norm()) + 1e-5, name
+
+
+def test_directional_finite_difference(E, world):
+    store, bs = world["store"], world["bs"]
+    m = _model(E)
+    b = _randomise_x(store.collate(torch.arange(bs)))
+    eng = E.StepEngine(m)
+    m.train()
+    eng.train_step(b)
+    params = [p for n, p in m.named_parameters()]
+    # entries move by ~0.1 % of their tensor's RMS: small enough that ReLU / L1 kinks crossed on the way stay a
+    # second-order effect, large enough that the loss difference stands above fp32 rounding
+    # (uphill: the sign of the gradient, so that the directional derivative is as large as the step allows)
+    direction = [torch.sign(p.grad) * float(p.detach().pow(2).mean().sqrt()) for p in params]
+    analytic = sum(float((p.grad.double() * d.double()).sum()) for p, d in zip(params, direction))
+
+    def loss_at(t):
+        with torch.no_grad():
+            for p, d in zip(params, direction):
+                p.add_(t * d)
+            val = float(eng.train_step(b))       # forward value only matters here
+            for p, d in zip(params, direction):
+                p.sub_(t * d)
+        return val
+    hstep = 2e-4
+    numeric = (loss_at(hstep) - loss_at(-hstep)) / (2 * hstep)
+    # fp32 forward: the quotient carries ~1e-6 * |loss| / h of rounding; kinks crossed inside [-h, h] add a little more
+    assert abs(numeric - analytic) <= 0.1 * abs(analytic) + 2e-3, (numeric, analytic)
