@@ -34,10 +34,9 @@ class _SumOfEmbeddings(torch.nn.Module):
 
     def forward(self, x):
         tables = getattr(self, self._tables)
-        out = 0
-        for i in range(x.shape[1]):
-            out = out + tables[i](x[:, i])
-        return out
+        if x.dim() != 2 or x.shape[1] > len(tables):
+            raise ValueError("expected integer features [n, <=%d]" % len(tables))
+        return ops.embedding_sum([t.weight for t in tables[:x.shape[1]]], x)       # one launch for all columns
 
 
 class AtomEncoder(_SumOfEmbeddings):

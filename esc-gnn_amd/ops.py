@@ -369,6 +369,63 @@ def embedding(weight, index):
     return _Embedding.apply(weight, index)
 
 
+class _EmbeddingSum(Function):
+    """out[r] = sum_j table[index[r, j] + offset_j]: the sum-of-embeddings encoders of the OGB models (AtomEncoder,
+    BondEncoder: ogb_mol_gnn.py:264-282 and ogb's BondEncoder) as ONE bag launch over the concatenated tables instead
+    of one lookup per feature column.  Entries of a row are added in column order starting from 0, i.e. exactly the
+    reference's `out = 0; for i: out = out + emb_i(x[:, i])`.  The CSC plan of the gradient depends only on the index
+    tensor: it is built once and cached on it (the bond features of a batch are looked up by every layer)."""
+
+    @staticmethod
+    def forward(ctx, table, index, dims):
+        _dev(table)
+        _on(table.device, index)
+        table = table.contiguous()
+        n, k = index.shape
+        H, dev = table.size(1), table.device
+        cache = getattr(index, "_esc_embed", None)
+        if cache is None or cache[0] != dims:
+            dims_t = torch.tensor(dims, dtype=torch.int64, device=dev)
+            if n and bool(((index < 0) | (index >= dims_t)).any()):        # one check per index tensor, not per lookup
+                raise IndexError("embedding index out of range")
+            offs = torch.zeros(k, dtype=torch.int64, device=dev)
+            offs[1:] = torch.cumsum(dims_t, 0)[:-1]
+            flat = (index + offs).reshape(-1)
+            order = torch.sort(flat, stable=True)[1]
+            rows = int(sum(dims))
+            col_ptr = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
+            col_ptr[1:] = torch.cumsum(torch.bincount(flat, minlength=rows), 0)
+            plan = dict(idx32=flat.to(torch.int32), row_ptr=torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev),
+                        ones=torch.ones(n * k, dtype=torch.int32, device=dev), col_ptr=col_ptr,
+                        c_row=torch.div(order, k, rounding_mode="floor").to(torch.int32), c_col=flat[order].to(torch.int32))
+            cache = (dims, plan)
+            index._esc_embed = cache
+        plan = cache[1]
+        out = torch.empty((n, H), dtype=torch.float32, device=dev)
+        nv.call("esc_bag_fwd", nv.ptr(table), H, nv.ptr(plan["row_ptr"]), nv.ptr(plan["idx32"]), nv.ptr(plan["ones"]), n,
+                nv.ptr(out), H, nv.stream())
+        ctx.plan, ctx.rows, ctx.H, ctx.nk = plan, table.size(0), H, n * k
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        g, ld = _rows(g.reshape(-1, ctx.H))
+        dw = torch.empty((ctx.rows, ctx.H), dtype=torch.float32, device=g.device)
+        scratch = torch.empty(max(1, nv.lib().esc_bag_bwd_scratch(ctx.nk, ctx.H)), dtype=torch.float32, device=g.device)
+        nv.call("esc_bag_bwd_table", nv.ptr(g), ld, ctx.H, nv.ptr(plan["col_ptr"]), nv.ptr(plan["c_row"]),
+                nv.ptr(plan["ones"]), nv.ptr(plan["c_col"]), ctx.nk, ctx.rows, nv.ptr(dw), nv.ptr(scratch), nv.stream())
+        return dw, None, None
+
+
+def embedding_sum(weights, index):
+    """sum_j weights[j][index[:, j]] (index: LongTensor [n, len(weights)])."""
+    if index.dim() != 2 or index.size(1) != len(weights):
+        raise ValueError("embedding_sum: index must be [n, %d]" % len(weights))
+    dims = tuple(int(w.size(0)) for w in weights)
+    return _EmbeddingSum.apply(torch.cat(list(weights), dim=0), index, dims)
+
+
 class _NeighbourSum(Function):
     """out[i] = sum_{k: dst_k=i} relu(x[src_k] (+ e_k)) — GINE aggregate without the self term and with an
     optional edge term: the per-distance message sum of GINEPLUS / NAIVEGINEPLUS
