@@ -144,7 +144,8 @@ static int g_use_side_stream = 0;     // esc_engine_set_side_stream(); measured 
 // (152 workgroups on 256 CUs) leave idle.  One event per dependency, no host synchronisation.
 struct EdgeStream {
   hipStream_t stream = nullptr;
-  hipEvent_t z_ready = nullptr, joined = nullptr, e_ready[ESC_MAX_LAYERS] = {}, de_ready[ESC_MAX_LAYERS] = {};
+  hipEvent_t z_ready = nullptr, joined = nullptr, e_ready[ESC_MAX_LAYERS] = {}, de_ready[ESC_MAX_LAYERS] = {},
+             agg_done[ESC_MAX_LAYERS] = {};
   bool ok = false;
 };
 static int g_edge_priority_low = 1;
@@ -163,6 +164,7 @@ static EdgeStream& edge_stream() {
     for (int l = 0; l < ESC_MAX_LAYERS; ++l) {
       good = good && hipEventCreateWithFlags(&es.e_ready[l], hipEventDisableTiming) == hipSuccess;
       good = good && hipEventCreateWithFlags(&es.de_ready[l], hipEventDisableTiming) == hipSuccess;
+      good = good && hipEventCreateWithFlags(&es.agg_done[l], hipEventDisableTiming) == hipSuccess;
     }
     es.ok = good;
   }
@@ -281,13 +283,18 @@ static int forward(const Ctx& c) {
     ESC_TRY(linear_bn(ce, y.Zb, H, m->zlin, y.zb0.scale, y.zb0.shift, E, y.Yz, m->zbn1, y.zb1));
   }                                                                       // z_emb = relu(Yz*scale+shift)
   if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, ce.s));
-  for (int l = 0; l < L; ++l) {
+  // The edge terms run two layers ahead of the node chain: e_{l+2} is queued behind the aggregate of layer l, so that a
+  // bandwidth-bound aggregate never shares the HBM with an edge-sized GEMM (both would only slow each other down).
+  auto edge_term = [&](int l) -> int {
     const esc_conv_t& cv = m->conv[l];
     const int64_t C = l == 0 ? y.C0 : H;
     if (mat) ESC_TRY(esc_linear_fwd(y.Zemb, H, cv.lin.w, H, cv.lin.b, nullptr, nullptr, E, C, H, y.e[l], C, nullptr, ce.s));
     else     ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], C, nullptr, ce.s));
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
-  }
+    return ESC_OK;
+  };
+  const int ahead = es.ok ? 2 : (int)L;          // one stream: all of them up front, in layer order
+  for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
   // ---- node pipeline
   // xs[0] = x_embedding(x) (reference :166) — side stream
   SideStream& ss = side_stream();
@@ -310,6 +317,10 @@ static int forward(const Ctx& c) {
     const int64_t ld_h = l == 0 ? y.C0 : W;
     if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    if (es.ok && l + 2 < (int)L) {
+      ESC_TRY(chain(es.agg_done[l], (hipStream_t)c.s, es.stream));
+      ESC_TRY(edge_term(l + 2));
+    }
     ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W));
   }
   // readout (reference :183-189) needs every slice of cat, including the side stream's
