@@ -115,25 +115,32 @@ def main():
         stats["edges"] += b.edge_index.size(1)
         stats["nnz"] += b.pos_enc.numel()
 
+    nxt = {"b": None}
+
     def step(i, count=False):
-        b = store.collate(batch_ids[i % nb])                # host ids: async pinned staging, no host/device sync
-        if engine is not None and world > 1:
-            # gradients of sum|err| (not the local mean): ONE RCCL all-reduce of grad ++ [n_local] gives the global
-            # sums, and the division by the global node count rides on the Adam launch
-            loss = engine.train_step(b, loss_denom=1)
-            opt.step(grad_denom=opt.all_reduce_sum(b.x.size(0)))
+        # host ids: async pinned staging, no host/device sync.  Engine path: the NEXT batch is collated between the two
+        # halves of the step, i.e. on the node stream while the edge pipeline finishes its backward
+        b = nxt["b"] if nxt["b"] is not None else store.collate(batch_ids[i % nb])
+        nxt["b"] = None
+        if engine is not None:
+            # world > 1: gradients of sum|err| (not the local mean): ONE RCCL all-reduce of grad ++ [n_local] gives the
+            # global sums, and the division by the global node count rides on the Adam launch
+            loss = engine.begin_step(b, loss_denom=1 if world > 1 else None)
+            nxt["b"] = store.collate(batch_ids[(i + 1) % nb])
+            engine.end_step()
+            if world > 1:
+                opt.step(grad_denom=opt.all_reduce_sum(b.x.size(0)))
+            else:
+                opt.step()
             if count:
                 tally(b)
             return loss
-        if engine is not None:
-            loss = engine.train_step(b)                     # forward + L1 + backward, gradients overwritten
-        else:
-            opt.zero_grad()
-            pred = model(b)
-            loss = E.ops.l1_loss(pred, b.y)
-            loss.backward()
-            if world > 1:                                   # ONE all-reduce: grad*n_local ++ [n_local]
-                opt.all_reduce_weighted(b.x.size(0))
+        opt.zero_grad()
+        pred = model(b)
+        loss = E.ops.l1_loss(pred, b.y)
+        loss.backward()
+        if world > 1:                                       # ONE all-reduce: grad*n_local ++ [n_local]
+            opt.all_reduce_weighted(b.x.size(0))
         opt.step()
         if count:
             tally(b)

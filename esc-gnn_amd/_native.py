@@ -69,6 +69,8 @@ SIGNATURES = {
     "esc_engine_set_gemm_stats": [I32],
     "esc_engine_workspace_floats": [P, I64, I64, I64],
     "esc_engine_train_step": [P, P, P, I64, P, P, P],
+    "esc_engine_train_step_begin": [P, P, P, I64, P, P, P],
+    "esc_engine_train_step_end": [],
     "esc_engine_predict": [P, P, P, P, P],
     "esc_l1_loss": [P, P, I64, I64, F32, P, P, P],
     "esc_bce_logits_loss": [P, P, I64, I64, P, P, P],

@@ -332,7 +332,30 @@ static int forward(const Ctx& c) {
   return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
 }
 
-static int backward(const Ctx& c) {
+// What esc_engine_train_step_begin leaves for esc_engine_train_step_end: the join with the edge stream and the
+// edge-side weight-gradient reductions.  Work the caller enqueues between the two calls (the next batch's collate)
+// runs on the node stream while the edge pipeline is still finishing the step.
+struct Pending {
+  bool open = false;
+  bool join = false;
+  hipStream_t stream = nullptr;
+  std::vector<esc_reduce_job> edge_jobs;
+};
+static Pending& pending() {
+  static thread_local Pending p;
+  return p;
+}
+static int finish_pending(Pending& p) {
+  if (!p.open) return ESC_OK;
+  p.open = false;
+  EdgeStream& es = edge_stream();
+  if (p.join && hipStreamWaitEvent(p.stream, es.joined, 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+  if (!p.edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(p.edge_jobs.data(), (int)p.edge_jobs.size(), p.stream));
+  p.edge_jobs.clear();
+  return ESC_OK;
+}
+
+static int backward(const Ctx& c, Pending* defer) {
   const esc_nested_gin_t* m = c.m;
   const esc_batch_t* b = c.b;
   const Layout& y = c.y;
@@ -392,13 +415,17 @@ static int backward(const Ctx& c) {
   // node-side reductions first (with an edge stream they overlap its tail), then join, then the edge-side ones
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
-  if (es.ok) {
-    ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));
-    if (!edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), c.s));
-  }
   if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_b, 0) != hipSuccess) {
     set_error("esc_engine: side-stream join failed");
     return ESC_ELAUNCH;
+  }
+  if (es.ok) {
+    if (hipEventRecord(es.joined, es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+    Pending local;
+    Pending& p = defer ? *defer : local;
+    p.open = true; p.join = true; p.stream = (hipStream_t)c.s;
+    p.edge_jobs.swap(edge_jobs);
+    if (!defer) return finish_pending(p);
   }
   return ESC_OK;
 }
@@ -442,8 +469,25 @@ int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_
   return plan_layout(m, N, E, Z, nullptr, true).total;
 }
 
+static int train_step_impl(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
+                           int64_t loss_denom, float* loss, float* pred, void* stream, Pending* defer);
+
 int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
                           int64_t loss_denom, float* loss, float* pred, void* stream) {
+  ESC_TRY(finish_pending(pending()));
+  return train_step_impl(m, b, workspace, loss_denom, loss, pred, stream, nullptr);
+}
+
+int esc_engine_train_step_begin(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
+                                int64_t loss_denom, float* loss, float* pred, void* stream) {
+  ESC_TRY(finish_pending(pending()));
+  return train_step_impl(m, b, workspace, loss_denom, loss, pred, stream, &pending());
+}
+
+int esc_engine_train_step_end(void) { return finish_pending(pending()); }
+
+static int train_step_impl(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
+                           int64_t loss_denom, float* loss, float* pred, void* stream, Pending* defer) {
   int rc = check(m, b, workspace, true);
   if (rc) return rc;
   ESC_REQUIRE(loss, "esc_engine_train_step: null loss pointer");
@@ -460,11 +504,12 @@ int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float
       return ESC_ELAUNCH;
     }
   }
-  return backward(c);
+  return backward(c, defer);
 }
 
 int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
                        void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check(m, b, workspace, false);
   if (rc) return rc;
   ESC_REQUIRE(pred, "esc_engine_predict: null output");

@@ -110,6 +110,7 @@ class StepEngine(object):
         d.lin1, d.bn_lin1, d.lin2 = _lin(m.lin1), _bn(m.bn_lin1), _lin(m.lin2)
         self._desc = d
         self._keep = [p for p in m.parameters()]
+        self._open = None
 
     def _batch(self, data, need_y):
         dev = self.model.lin1.weight.device
@@ -140,18 +141,29 @@ class StepEngine(object):
             self._ws = torch.empty(int(need * 1.25), dtype=torch.float32, device=self.model.lin1.weight.device)
         return self._ws
 
-    def train_step(self, data, loss_denom=None, return_pred=False):
+    def train_step(self, data, loss_denom=None, return_pred=False, _entry="esc_engine_train_step"):
         """forward + L1 + backward; gradients land in the parameters' .grad (overwritten). Returns loss (0-d)."""
         dev = self.model.lin1.weight.device
         b, keep = self._batch(data, True)
         ws = self._workspace(b)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         pred = torch.empty(b.N, dtype=torch.float32, device=dev) if return_pred else None
-        nv.call("esc_engine_train_step", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(),
+        nv.call(_entry, ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(),
                 int(loss_denom or 0), loss.data_ptr(), nv.ptr(pred), nv.stream())
+        self._open = (keep, ws) if _entry.endswith("_begin") else None     # operands stay alive until end_step
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)
         return (loss.view(()), pred.view(-1, 1)) if return_pred else loss.view(())
+
+    def begin_step(self, data, loss_denom=None, return_pred=False):
+        """train_step up to (not including) the join with the edge stream: what the caller enqueues next on the current
+        stream — typically `store.collate(next_ids)` — overlaps the tail of the edge pipeline.  Call end_step() before
+        using the gradients / the loss."""
+        return self.train_step(data, loss_denom, return_pred, _entry="esc_engine_train_step_begin")
+
+    def end_step(self):
+        nv.call("esc_engine_train_step_end")
+        self._open = None
 
     @torch.no_grad()
     def predict(self, data):

@@ -229,26 +229,41 @@ def main(argv=None):
     engine = StepEngine(model)         # one native call per step; same parameters / .grad slots / BN buffers
     gen = torch.Generator().manual_seed(args.seed)
 
-    def batches(store, shuffle):
+    def shards(store, shuffle):
         G = len(store)
         order = torch.randperm(G, generator=gen) if shuffle else torch.arange(G)
         for i in range(0, G, args.batch_size):
             ids = order[i:i + args.batch_size]
             lo, hi = shard_slice(ids.numel(), rank, world)           # shard the global batch by graph
             if hi > lo:
-                yield store.collate(ids[lo:hi])
+                yield ids[lo:hi]
+
+    def batches(store, shuffle):
+        for ids in shards(store, shuffle):
+            yield store.collate(ids)
 
     def train(epoch):
         model.train()
         loss_all = torch.zeros((), device=device)
-        for data in batches(stores[0], True):
+        todo = shards(stores[0], True)
+        first = next(todo, None)
+        data = None if first is None else stores[0].collate(first)
+        while data is not None:
             n_local = data.y.size(0)
-            if world > 1:     # sum-gradients, one all-reduce of grad ++ [n_local], division inside the Adam launch
-                loss_all += engine.train_step(data, loss_denom=1)
+            # forward + L1Loss + backward (reference :494-503); the next batch is collated between the two halves of
+            # the step, while the edge pipeline finishes.  world > 1: sum-gradients, one all-reduce of grad ++ [n_local],
+            # division inside the Adam launch
+            loss = engine.begin_step(data, loss_denom=1 if world > 1 else None)
+            ids = next(todo, None)
+            upcoming = None if ids is None else stores[0].collate(ids)
+            engine.end_step()
+            if world > 1:
+                loss_all += loss
                 optimizer.step(grad_denom=optimizer.all_reduce_sum(n_local))
             else:
-                loss_all += engine.train_step(data) * n_local   # forward + L1Loss + backward (reference :494-503)
+                loss_all += loss * n_local
                 optimizer.step()
+            data = upcoming
         if world > 1:
             dist.all_reduce(loss_all)
         return float(loss_all) / n_train_targets

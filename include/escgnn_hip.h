@@ -257,6 +257,13 @@ int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_
 int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
                           int64_t loss_denom, float* loss, float* pred, void* stream);
 /* eval-mode forward (running statistics, no gradient state kept): pred float[N] */
+/* The same step in two halves: _begin enqueues everything except the final join with the edge stream and the
+ * edge-side weight-gradient reductions; _end (same thread) enqueues those.  Whatever the caller enqueues on `stream`
+ * in between (the next batch's collate) runs while the edge pipeline is still finishing.  The gradients and the loss
+ * are complete only after _end; a following esc_engine_train_step* call closes an open step by itself. */
+int esc_engine_train_step_begin(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
+                                int64_t loss_denom, float* loss, float* pred, void* stream);
+int esc_engine_train_step_end(void);
 int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
                        void* stream);
 

@@ -227,3 +227,27 @@ def test_directional_finite_difference(E, world):
     numeric = (loss_at(hstep) - loss_at(-hstep)) / (2 * hstep)
     # fp32 forward: the quotient carries ~1e-6 * |loss| / h of rounding; kinks crossed inside [-h, h] add a little more
     assert abs(numeric - analytic) <= 0.1 * abs(analytic) + 2e-3, (numeric, analytic)
+
+
+def test_split_step_equals_single_call(E, world):
+    """begin_step + (next batch's collate on the same stream) + end_step == train_step, bit for bit; an unfinished
+    step is closed by the next engine call."""
+    store, bs = world["store"], world["bs"]
+    eng = E.StepEngine(_model(E))
+    b = _randomise_x(store.collate(torch.arange(bs)))
+    l1 = eng.train_step(b)
+    g1 = [p.grad.clone() for p in eng.model.parameters()]
+    for p in eng.model.parameters():
+        p.grad.zero_()
+    l2 = eng.begin_step(b)
+    other = store.collate(torch.arange(bs, 2 * bs))          # overlaps the edge tail
+    eng.end_step()
+    assert float(l1) == float(l2)
+    for (name, p), g in zip(eng.model.named_parameters(), g1):
+        assert torch.equal(p.grad, g), name
+    eng.begin_step(b)                                          # left open on purpose
+    pred = eng.predict(other)                                  # closes it first
+    torch.cuda.synchronize()
+    for (name, p), g in zip(eng.model.named_parameters(), g1):
+        assert torch.equal(p.grad, g), name
+    assert bool(torch.isfinite(pred).all())
