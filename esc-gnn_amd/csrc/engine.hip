@@ -404,11 +404,12 @@ static int backward(const Ctx& c, Pending* defer) {
   // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order); it overlaps the
   // x_embedding backward queued above on the node stream
   const bool mat = g_materialise_edge_act != 0;
-  ESC_TRY(esc_bn_bwd(y.Yz, H, mat ? y.Zemb : nullptr, H, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma,
+  // (the ReLU mask is recomputed from the pre-BN value even when the activation was materialised: one array less to read)
+  ESC_TRY(esc_bn_bwd(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma,
                      m->zbn1.beta, 1, y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, ce.y.bn_scratch, ce.s));
   if (mat) ESC_TRY(linear_backward(ce, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
   else     ESC_TRY(linear_backward(ce, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
-  ESC_TRY(esc_bn_bwd(y.Zb, H, mat ? y.A0 : nullptr, H, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
+  ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, ce.y.bn_scratch, ce.s));
   ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
                             y.bag_scratch, ce.s));

@@ -355,6 +355,69 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// Row-strided float4 form of the two elementwise passes above: a lane owns one column quad for the whole launch, so
+// the per-column coefficients are loaded ONCE as float4 (the flat-index kernels re-read ~20 scalars per element) and a
+// wave keeps 4 rows x 2-3 arrays in flight.  Edge-sized BatchNorm backward: 17 -> 11 us.
+template <int ACT, bool HAS_Y>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ Y, int64_t ldy,
+                                                         const float* __restrict__ dY, int64_t ldg, int M, int C,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float2* __restrict__ coef,
+                                                         float* __restrict__ dX, int64_t ldd) {
+  constexpr int relu = ACT;
+  const int c = (blockIdx.x * 64 + lane_id()) * 4;
+  if (c >= C) return;
+  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int P = gridDim.y * 4;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+  const float4 ga = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 be = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 k01 = *reinterpret_cast<const float4*>(coef + c), k23 = *reinterpret_cast<const float4*>(coef + c + 2);
+  const float4 a = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
+#pragma unroll 4
+  for (int r = slot; r < M; r += P) {
+    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
+    float4 g = *reinterpret_cast<const float4*>(dY + (size_t)r * ldg + c);
+    const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
+    if constexpr (ACT != 0) {
+      if constexpr (HAS_Y) {
+        const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+        g.x *= act_grad_from_out(y.x, relu); g.y *= act_grad_from_out(y.y, relu);
+        g.z *= act_grad_from_out(y.z, relu); g.w *= act_grad_from_out(y.w, relu);
+      } else {
+        g.x *= act_grad_from_pre(fmaf(xh.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(fmaf(xh.y, ga.y, be.y), relu);
+        g.z *= act_grad_from_pre(fmaf(xh.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(fmaf(xh.w, ga.w, be.w), relu);
+      }
+    }
+    // same expression as bn_bwd_apply_kernel: gamma * invstd * (g - k.x - xhat * k.y)
+    *reinterpret_cast<float4*>(dX + (size_t)r * ldd + c) =
+        make_float4(a.x * (g.x - k01.x - xh.x * k01.y), a.y * (g.y - k01.z - xh.y * k01.w),
+                    a.z * (g.z - k23.x - xh.z * k23.y), a.w * (g.w - k23.z - xh.w * k23.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_rows(const float* __restrict__ X, int64_t ldx, int M, int C,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int relu,
+                                                       float* __restrict__ Y, int64_t ldy) {
+  const int c = (blockIdx.x * 64 + lane_id()) * 4;
+  if (c >= C) return;
+  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int P = gridDim.y * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+#pragma unroll 4
+  for (int r = slot; r < M; r += P) {
+    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
+    *reinterpret_cast<float4*>(Y + (size_t)r * ldy + c) =
+        make_float4(act_fwd(fmaf(x.x, sc.x, sh.x), relu), act_fwd(fmaf(x.y, sc.y, sh.y), relu),
+                    act_fwd(fmaf(x.z, sc.z, sh.z), relu), act_fwd(fmaf(x.w, sc.w, sh.w), relu));
+  }
+}
+
 // y = relu?(x*scale + shift): materialises a consumer-side-fused BatchNorm(+ReLU) output
 template <int VEC>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int C,
@@ -465,8 +528,12 @@ int esc_affine_act(const float* X, int64_t ld_x, int64_t M, int64_t C, const flo
                    aligned16(scale) && aligned16(shift);
   const int64_t work = M * (vec ? C / 4 : C);
   const unsigned blocks = (unsigned)(cdiv(work, 256) < 4096 ? cdiv(work, 256) : 4096);
-  if (vec) esc::launch(ESC_K_NORM, affine_act_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
-  else     esc::launch(ESC_K_NORM, affine_act_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
+  if (vec && M < (1LL << 31)) {
+    const unsigned rb = (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048);        // 4 rows per wave and pass
+    esc::launch(ESC_K_NORM, affine_act_rows, dim3((unsigned)cdiv(C, 256), rb), dim3(256), 0, s, X, ld_x, (int)M, (int)C, scale, shift, relu, Y, ld_y);
+  }
+  else if (vec) esc::launch(ESC_K_NORM, affine_act_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
+  else          esc::launch(ESC_K_NORM, affine_act_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
   ESC_CHECK_LAUNCH("esc_affine_act");
   return ESC_OK;
 }
@@ -526,7 +593,16 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   if (relu == 0)      ESC_BWD_APPLY(V, 0, false);                                           \
   else if (relu == 1) { if (Y) ESC_BWD_APPLY(V, 1, true); else ESC_BWD_APPLY(V, 1, false); } \
   else                { if (Y) ESC_BWD_APPLY(V, 2, true); else ESC_BWD_APPLY(V, 2, false); }
-  if (vec) { ESC_BWD_APPLY_V(4) } else { ESC_BWD_APPLY_V(1) }
+  const bool rows_form = vec && aligned16(mean) && aligned16(invstd) && (!beta || aligned16(beta)) && aligned16(coef);
+  if (rows_form) {
+    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048));
+#define ESC_BWD_ROWS(A, H) esc::launch(ESC_K_NORM, bn_bwd_apply_rows<A, H>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, coef, dX, ld_dx)
+    if (relu == 0)      ESC_BWD_ROWS(0, false);
+    else if (relu == 1) { if (Y) ESC_BWD_ROWS(1, true); else ESC_BWD_ROWS(1, false); }
+    else                { if (Y) ESC_BWD_ROWS(2, true); else ESC_BWD_ROWS(2, false); }
+#undef ESC_BWD_ROWS
+  }
+  else if (vec) { ESC_BWD_APPLY_V(4) } else { ESC_BWD_APPLY_V(1) }
 #undef ESC_BWD_APPLY_V
 #undef ESC_BWD_APPLY
   ESC_CHECK_LAUNCH("esc_bn_bwd.apply");
