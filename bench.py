@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--lr", type=float, default=1e-2)
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no_breakdown", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="esc_tune_set(knob, value), repeatable")
     ap.add_argument("--streams", type=int, default=None,
                     help="esc_engine_set_side_stream mode (default: the library's; 0 = everything on one stream)")
     ap.add_argument("--path", choices=("engine", "autograd"), default="engine",
@@ -84,6 +85,9 @@ def main():
 
     if args.streams is not None:
         nv.call("esc_engine_set_side_stream", args.streams)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        nv.call("esc_tune_set", int(k), int(v))
     torch.manual_seed(0)
     # ---- dataset: synthetic graphs -> HIP feature build -> HBM-resident store -----------------------
     t0 = time.time()

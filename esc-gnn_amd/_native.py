@@ -41,6 +41,8 @@ SIGNATURES = {
     "esc_bag_fwd": [P, I64, P, P, P, I64, P, I64, P],
     "esc_bag_bwd_scratch": [I64, I64],
     "esc_bag_bwd_table": [P, I64, I64, P, P, P, P, I64, I64, P, P, P],
+    "esc_bag_bwd_classify": [P, I64, I64, I64, P, P],
+    "esc_bag_bwd_table_rows": [P, I64, I64, P, P, P, P, I64, I64, I64, I32, P, P, P],
     "esc_gine_aggregate_fwd": [P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P],
     "esc_gine_aggregate_bwd": [P, I64, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P],
     "esc_reduce_sum": [P, I64, P, P],

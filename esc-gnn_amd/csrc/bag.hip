@@ -113,14 +113,10 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
 constexpr int BAG_CH = 64;
 
 template <int VEC>
-__global__ __launch_bounds__(256) void bag_bwd_pass1(const float* __restrict__ dz, int64_t ld_dz, int H,
-                                                     const int* __restrict__ col_ptr,
-                                                     const int* __restrict__ c_row,
-                                                     const int* __restrict__ c_val,
-                                                     const int* __restrict__ c_col, int Z,
-                                                     float* __restrict__ dtable,
-                                                     float* __restrict__ partials) {
-  const int chunk = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+__device__ __forceinline__ void bag_chunk(int chunk, const float* __restrict__ dz, int64_t ld_dz, int H,
+                                          const int* __restrict__ col_ptr, const int* __restrict__ c_row,
+                                          const int* __restrict__ c_val, const int* __restrict__ c_col, int Z,
+                                          float* __restrict__ dtable, float* __restrict__ partials) {
   const int beg = chunk * BAG_CH;
   if (beg >= Z) return;
   const int end = min(beg + BAG_CH, Z);
@@ -162,6 +158,67 @@ __global__ __launch_bounds__(256) void bag_bwd_pass1(const float* __restrict__ d
       }
     }
   }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bag_bwd_pass1(const float* __restrict__ dz, int64_t ld_dz, int H,
+                                                     const int* __restrict__ col_ptr,
+                                                     const int* __restrict__ c_row,
+                                                     const int* __restrict__ c_val,
+                                                     const int* __restrict__ c_col, int Z,
+                                                     float* __restrict__ dtable,
+                                                     float* __restrict__ partials) {
+  const int chunk = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  bag_chunk<VEC>(chunk, dz, ld_dz, H, col_ptr, c_row, c_val, c_col, Z, dtable, partials);
+}
+
+// ---- L2-local scheduling of pass 1 -----------------------------------------------------------------------
+// The gradient rows dz (E x H, 15.6 MB at cfg1) do not fit one XCD's 4 MB L2, and a column's entries walk the rows in
+// ascending order: 94 % of the 64-entry chunks touch a single eighth of the rows (the histogram has few, long columns).
+// Chunks are therefore bucketed by the row eighth of their middle entry, and workgroup b — which shares an XCD, hence
+// an L2, with every workgroup b' = b (mod 8) — only takes chunks of bucket b % 8: each L2 then serves ~2 MB of rows at
+// ~36x reuse instead of streaming all 15.6 MB from HBM / Infinity Cache.  Placement affects speed only: every chunk is
+// still processed exactly once and writes its own slots.
+__global__ __launch_bounds__(256) void bag_bwd_classify(const int* __restrict__ c_row, int Z, int rows, int chunks,
+                                                        int* __restrict__ order, int* __restrict__ bucket_cnt) {
+  // one thread per chunk, many workgroups (the scattered middle-row reads miss: one CU alone needs ~20 us for them);
+  // per wave and key ONE device atomic reserves the slots, the list of bucket k is order[k*chunks ...] in arrival
+  // order — which does not matter: every chunk is processed once and writes its own slots
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = lane_id();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned eighth = ((unsigned)rows + 7u) / 8u;        // key = row / ceil(rows/8): 0..7
+  int key = -1;
+  if (q < chunks) {
+    const int beg = q * BAG_CH, end = min(beg + BAG_CH, Z);
+    key = min(7, (int)((unsigned)c_row[(beg + end) >> 1] / eighth));
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const unsigned long long m = __ballot(key == k);
+    if (m == 0) continue;
+    int at = 0;
+    if (lane == 0) at = atomicAdd(&bucket_cnt[k], __popcll(m));
+    at = __shfl(at, 0, 64);
+    if (key == k) order[(size_t)k * chunks + at + __popcll(m & below)] = q;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bag_bwd_pass1_local(const float* __restrict__ dz, int64_t ld_dz, int H,
+                                                           const int* __restrict__ col_ptr,
+                                                           const int* __restrict__ c_row,
+                                                           const int* __restrict__ c_val,
+                                                           const int* __restrict__ c_col, int Z,
+                                                           float* __restrict__ dtable, float* __restrict__ partials,
+                                                           const int* __restrict__ order,
+                                                           const int* __restrict__ bucket_cnt, int chunks) {
+  const int group = blockIdx.x & 7;                         // workgroups of one group share an XCD
+  const int n = uniform(bucket_cnt[group]);
+  const int* __restrict__ mine = order + (size_t)group * chunks;
+  const int stride = (int)(gridDim.x >> 3) * 4;
+  for (int slot = (int)(blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6); slot < n; slot += stride)
+    bag_chunk<VEC>(uniform(mine[slot]), dz, ld_dz, H, col_ptr, c_row, c_val, c_col, Z, dtable, partials);
 }
 
 // Pass 2: one WORKGROUP per column.  Its 4 waves take the column's chunk partials round-robin
@@ -239,11 +296,53 @@ int esc_bag_fwd(const float* table, int64_t H, const int32_t* row_ptr, const int
   return ESC_OK;
 }
 
-int64_t esc_bag_bwd_scratch(int64_t Z, int64_t H) { return 2 * esc::cdiv(Z, esc::BAG_CH) * H; }
+int64_t esc_bag_bwd_scratch(int64_t Z, int64_t H) {      // chunk partials + (chunk order, bucket starts) of the local schedule
+  return 2 * esc::cdiv(Z, esc::BAG_CH) * H + 8 * esc::cdiv(Z, esc::BAG_CH) + 64;
+}
+
+static int bag_bwd_impl(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
+                        const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
+                        int64_t n_cols, int64_t rows, int classified, float* dtable, float* partials, void* stream);
+
+static inline bool bag_local_schedule(int64_t Z, int64_t H, int64_t rows) {
+  // rows given, the gradient matrix larger than one XCD's L2, enough chunks to spread over 8 groups
+  return rows > 0 && rows * H * (int64_t)sizeof(float) > (4 << 20) && esc::cdiv(Z, esc::BAG_CH) >= 64;
+}
+
+int esc_bag_bwd_classify(const int32_t* c_row, int64_t Z, int64_t H, int64_t rows, float* partials, void* stream) {
+  ESC_REQUIRE(Z == 0 || (c_row && partials), "esc_bag_bwd_classify: null pointer");
+  ESC_REQUIRE(H > 0 && Z >= 0 && rows >= 0 && rows < (1LL << 28) && Z < (1LL << 31) - 64, "esc_bag_bwd_classify: bad sizes");
+  if (!bag_local_schedule(Z, H, rows)) return ESC_OK;        // esc_bag_bwd_table_rows will not use a schedule either
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t chunks = esc::cdiv(Z, esc::BAG_CH);
+  int* order = reinterpret_cast<int*>(partials + 2 * chunks * H);       // [8][chunks]
+  int* bucket_cnt = order + 8 * chunks;                                 // [8]
+  if (hipMemsetAsync(bucket_cnt, 0, 8 * sizeof(int), s) != hipSuccess) {
+    esc::set_error("esc_bag_bwd_classify: memset failed");
+    return ESC_ELAUNCH;
+  }
+  esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_classify, dim3((unsigned)esc::cdiv(chunks, 256)), dim3(256), 0, s, c_row, (int)Z, (int)rows, (int)chunks, order, bucket_cnt);
+  ESC_CHECK_LAUNCH("esc_bag_bwd_classify");
+  return ESC_OK;
+}
 
 int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
                       const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
                       int64_t n_cols, float* dtable, float* partials, void* stream) {
+  return bag_bwd_impl(dz, ld_dz, H, col_ptr, c_row, c_val, c_col, Z, n_cols, 0, 0, dtable, partials, stream);
+}
+
+int esc_bag_bwd_table_rows(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
+                           const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
+                           int64_t n_cols, int64_t rows, int classified, float* dtable, float* partials,
+                           void* stream) {
+  ESC_REQUIRE(rows >= 0 && rows < (1LL << 28), "esc_bag_bwd_table_rows: bad row count");
+  return bag_bwd_impl(dz, ld_dz, H, col_ptr, c_row, c_val, c_col, Z, n_cols, rows, classified, dtable, partials, stream);
+}
+
+static int bag_bwd_impl(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
+                        const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
+                        int64_t n_cols, int64_t rows, int classified, float* dtable, float* partials, void* stream) {
   ESC_REQUIRE(dz && col_ptr && dtable, "esc_bag_bwd_table: null pointer");
   ESC_REQUIRE(Z == 0 || (c_row && c_val && c_col && partials), "esc_bag_bwd_table: null entry arrays");
   ESC_REQUIRE(H > 0 && Z >= 0 && n_cols > 0 && ld_dz >= H, "esc_bag_bwd_table: bad sizes");
@@ -253,7 +352,17 @@ int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* 
   if (Z > 0) {
     const int64_t chunks = esc::cdiv(Z, esc::BAG_CH);
     const int64_t blocks = esc::cdiv(chunks, 4);
-    if (vec)
+    if (bag_local_schedule(Z, H, rows)) {          // chunks bucketed by row eighth (see bag_bwd_classify)
+      if (!classified) ESC_REQUIRE(esc_bag_bwd_classify(c_row, Z, H, rows, partials, stream) == ESC_OK, "%s", esc_last_error());
+      int* order = reinterpret_cast<int*>(partials + 2 * chunks * H);
+      int* bucket_cnt = order + 8 * chunks;
+      const unsigned per_group = (unsigned)(esc::cdiv(esc::cdiv(chunks, 8) * 5 / 4 + 4, 4));   // 25 % slack; the kernel strides beyond
+      if (vec)
+        esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass1_local<4>, dim3(per_group * 8), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials, (const int*)order, (const int*)bucket_cnt, (int)chunks);
+      else
+        esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass1_local<1>, dim3(per_group * 8), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials, (const int*)order, (const int*)bucket_cnt, (int)chunks);
+      ESC_CHECK_LAUNCH("esc_bag_bwd_table.pass1_local");
+    } else if (vec)
       esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass1<4>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);
     else
       esc::launch(ESC_K_BAG_BWD, esc::bag_bwd_pass1<1>, dim3(blocks), dim3(256), 0, s, dz, ld_dz, (int)H, col_ptr, c_row, c_val, c_col, (int)Z, dtable, partials);

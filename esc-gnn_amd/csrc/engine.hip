@@ -295,7 +295,9 @@ static int forward(const Ctx& c) {
   };
   const int ahead = es.ok ? 2 : (int)L;          // one stream: all of them up front, in layer order
   for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
-  // ---- node pipeline
+  // ---- node pipeline (first, while it would otherwise wait for the first edge term: the chunk schedule of the bag
+  // gradient, which depends on the batch's index arrays only)
+  if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, c.s));
   // xs[0] = x_embedding(x) (reference :166) — side stream
   SideStream& ss = side_stream();
   if (ss.ok) {
@@ -411,8 +413,8 @@ static int backward(const Ctx& c, Pending* defer) {
   else     ESC_TRY(linear_backward(ce, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
   ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, ce.y.bn_scratch, ce.s));
-  ESC_TRY(esc_bag_bwd_table(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, m->dz_table,
-                            y.bag_scratch, ce.s));
+  ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E,
+                                 1, m->dz_table, y.bag_scratch, ce.s));
   // node-side reductions first (with an edge stream they overlap its tail), then join, then the edge-side ones
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));

@@ -67,9 +67,9 @@ class _Bag(Function):
         dz, ld = _rows(dz)
         dtable = torch.empty((rows, H), dtype=torch.float32, device=dz.device)
         scratch = torch.empty(max(1, nv.lib().esc_bag_bwd_scratch(plan.nnz, H)), dtype=torch.float32, device=dz.device)
-        nv.call("esc_bag_bwd_table", nv.ptr(dz), ld, H, nv.ptr(plan.col_ptr), nv.ptr(plan.col_row),
-                nv.ptr(plan.col_val), nv.ptr(plan.col_col), plan.nnz, rows, nv.ptr(dtable), nv.ptr(scratch),
-                nv.stream())
+        nv.call("esc_bag_bwd_table_rows", nv.ptr(dz), ld, H, nv.ptr(plan.col_ptr), nv.ptr(plan.col_row),
+                nv.ptr(plan.col_val), nv.ptr(plan.col_col), plan.nnz, rows, plan.num_edges, 0, nv.ptr(dtable),
+                nv.ptr(scratch), nv.stream())
         return dtable, None
 
 

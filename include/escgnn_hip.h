@@ -50,6 +50,15 @@ int64_t esc_bag_bwd_scratch(int64_t Z, int64_t H);
 int esc_bag_bwd_table(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
                       const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
                       int64_t n_cols, float* dtable, float* partials, void* stream);
+/* the same with the row count of dz given: when dz exceeds one XCD's L2 the 64-entry chunks of pass 1 are bucketed by
+ * the row eighth they touch and each bucket is served by workgroups that share an XCD (L2-local schedule; identical
+ * results).  The bucketing depends on the index arrays only: esc_bag_bwd_classify may run it ahead of time into the
+ * same scratch (classified = 1 then skips it).  Scratch as esc_bag_bwd_scratch. */
+int esc_bag_bwd_classify(const int32_t* c_row, int64_t Z, int64_t H, int64_t rows, float* partials, void* stream);
+int esc_bag_bwd_table_rows(const float* dz, int64_t ld_dz, int64_t H, const int32_t* col_ptr,
+                           const int32_t* c_row, const int32_t* c_val, const int32_t* c_col, int64_t Z,
+                           int64_t n_cols, int64_t rows, int classified, float* dtable, float* partials,
+                           void* stream);
 
 /* ---- a-8 GINE aggregate (PyG GINEConv propagate; run_graphcount.py:161,169;
  * semantics GraphGPS/graphgps/layer/gine_conv_layer.py:56-84) -------------------------------
