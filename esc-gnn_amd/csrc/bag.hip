@@ -131,6 +131,26 @@ __device__ __forceinline__ void bag_chunk(int chunk, const float* __restrict__ d
       float acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+      // 8 gradient rows in flight per wave (loads first, then the fmas in entry order: same sums as one by one)
+      for (; j + 8 <= seg_end; j += 8) {
+        float w[8][VEC], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = uniform(c_row[j + u]);
+          v[u] = (float)uniform(c_val[j + u]);
+          const float* p = dz + (size_t)r * ld_dz + c0;
+          if constexpr (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(p);
+            w[u][0] = q.x; w[u][1] = q.y; w[u][2] = q.z; w[u][3] = q.w;
+          } else {
+            w[u][0] = *p;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) acc[t] = fmaf(w[u][t], v[u], acc[t]);
+      }
 #pragma unroll 4
       for (; j < seg_end; ++j) {
         const int r = uniform(c_row[j]);
