@@ -600,8 +600,15 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceJobs t) {
   if (i < nw) {
     if (t.vec[j]) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-      for (int k = 0; k < q.splits; ++k) {
+      int k = 0;
+      for (; k + 8 <= q.splits; k += 8) {        // 8 slab reads in flight per thread, added in split order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q.slabs + (size_t)(k + u) * q.n + 4 * i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; k < q.splits; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(q.slabs + (size_t)k * q.n + 4 * i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
