@@ -64,6 +64,8 @@ SIGNATURES = {
     "esc_bn_stats_from_partials": [P, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P],
     "esc_bn_apply": [P, I64, I64, I64, P, P, P, P, I32, P, I64, P],
     "esc_bn_bwd": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, I64, P, P, P, P],
+    "esc_bn_bwd_sums": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, P, P, P, P],
+    "esc_bn_bwd_apply": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, P, I64, P],
     "esc_affine_act": [P, I64, I64, I64, P, P, I32, P, I64, P],
     "esc_bn_eval_coef": [P, P, P, P, F32, I64, P, P, P],
     "esc_engine_set_side_stream": [I32],

@@ -547,22 +547,19 @@ int esc_bn_eval_coef(const float* running_mean, const float* running_var, const 
   return ESC_OK;
 }
 
-int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
-               int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
-               const float* gamma, const float* beta, int relu, float* dX, int64_t ld_dx, float* dgamma,
-               float* dbeta, float* scratch, void* stream) {
-  ESC_REQUIRE(X && dY && dX && mean && invstd && scratch, "esc_bn_bwd: null pointer");
-  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && (!Y || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd: bad sizes");
-  hipStream_t s = (hipStream_t)stream;
+// column sums of the BatchNorm backward: coef[c] = (sum g, sum g*xhat) / divisor, dgamma = sum g*xhat, dbeta = sum g
+// (g = dY * act'(.)).  divisor = M for the local BatchNorm; 1 when the sums are still to be all-reduced (SyncBN).
+static int bn_bwd_reduce(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY, int64_t ld_dy,
+                         int64_t M, int64_t C, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, int relu, int64_t divisor, bool allow_fuse, float* dgamma, float* dbeta,
+                         float2* partial, float2* coef, hipStream_t s) {
   const bool wide = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (!Y || ld_y % 4 == 0) && aligned16(X) &&
                     aligned16(dY) && (!Y || aligned16(Y)) && aligned16(mean) && aligned16(invstd) &&
-                    (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && aligned16(scratch);
-  // node-sized inputs: few fat workgroups (>= 32 rows each) whose last one folds the <= 64 slots itself;
+                    (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && aligned16(partial);
+  // node-sized inputs: few fat workgroups (>= 32 rows each) whose last one folds the <= 64 slots itself (knob 8);
   // edge-sized: many workgroups + a wide finalize launch (one workgroup cannot pull hundreds of slots quickly)
-  const bool fuse = wide && M <= 4096 && last_block_finalize();
+  const bool fuse = allow_fuse && wide && M <= 4096 && divisor == M && last_block_finalize();
   const int rb = fuse ? (int)(cdiv(M, 32) < 64 ? cdiv(M, 32) : 64) : rowblocks(M, wide, true);
-  float2* partial = (float2*)scratch;
-  float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
   if (wide) {
     const dim3 grid((unsigned)cdiv(C, 256), rb);
     unsigned* tk = fuse ? tickets((int)grid.x) : nullptr;
@@ -574,15 +571,22 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
 #undef ESC_BWD_PARTIAL
     if (!fuse) {
       ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
-      esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb, dgamma, dbeta, coef);
+      esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)divisor, (int)C, rb, dgamma, dbeta, coef);
     }
   }
   else {
     esc::launch(ESC_K_NORM, bn_bwd_partial_kernel, dim3((unsigned)cdiv(C, 64), rb), dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, relu, gamma, beta, partial);
     ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
-    esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)M, (int)C, rb * 4, dgamma, dbeta, coef);
+    esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, partial, (int)divisor, (int)C, rb * 4, dgamma, dbeta, coef);
   }
   ESC_CHECK_LAUNCH("esc_bn_bwd.finalize");
+  return ESC_OK;
+}
+
+// dX = gamma * invstd * (g - coef.x - xhat * coef.y)
+static int bn_bwd_apply_impl(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY, int64_t ld_dy,
+                             int64_t M, int64_t C, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, int relu, const float2* coef, float* dX, int64_t ld_dx, hipStream_t s) {
   const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) && (!Y || ld_y % 4 == 0) &&
                    aligned16(X) && aligned16(dY) && aligned16(dX) && (!Y || aligned16(Y)) &&
                    (!gamma || aligned16(gamma));
@@ -607,6 +611,40 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
 #undef ESC_BWD_APPLY
   ESC_CHECK_LAUNCH("esc_bn_bwd.apply");
   return ESC_OK;
+}
+
+int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
+               int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
+               const float* gamma, const float* beta, int relu, float* dX, int64_t ld_dx, float* dgamma,
+               float* dbeta, float* scratch, void* stream) {
+  ESC_REQUIRE(X && dY && dX && mean && invstd && scratch, "esc_bn_bwd: null pointer");
+  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && (!Y || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  float2* partial = (float2*)scratch;
+  float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
+  int rc = bn_bwd_reduce(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, M, true, dgamma, dbeta, partial, coef, s);
+  if (rc != ESC_OK) return rc;
+  return bn_bwd_apply_impl(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, coef, dX, ld_dx, s);
+}
+
+int esc_bn_bwd_sums(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
+                    int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, int relu, float* sums, float* dgamma,
+                    float* dbeta, float* scratch, void* stream) {
+  ESC_REQUIRE(X && dY && sums && mean && invstd && scratch, "esc_bn_bwd_sums: null pointer");
+  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && (!Y || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd_sums: bad sizes");
+  return bn_bwd_reduce(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, 1, false, dgamma, dbeta,
+                       (float2*)scratch, (float2*)sums, (hipStream_t)stream);
+}
+
+int esc_bn_bwd_apply(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
+                     int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int relu, const float* coef, float* dX,
+                     int64_t ld_dx, void* stream) {
+  ESC_REQUIRE(X && dY && dX && mean && invstd && coef, "esc_bn_bwd_apply: null pointer");
+  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && (!Y || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd_apply: bad sizes");
+  return bn_bwd_apply_impl(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, (const float2*)coef, dX,
+                           ld_dx, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -29,6 +29,16 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
         """fuse_relu: False/None | True/'relu' | 'elu' — the activation module that follows in the reference."""
         super().__init__(num_features, eps=eps, momentum=momentum)
         self.fuse_relu = self.ACT[fuse_relu]
+        self.sync_group = False        # False: per-rank statistics; None / a ProcessGroup: statistics over that group
+
+    @staticmethod
+    def convert_sync(module, group=None):
+        """Switch every esc BatchNorm1d under `module` to statistics over all ranks of `group` (default group if None)
+        — the counterpart of torch.nn.SyncBatchNorm.convert_sync_batchnorm for graph-sharded data parallelism."""
+        for m in module.modules():
+            if isinstance(m, BatchNorm1d):
+                m.sync_group = group
+        return module
 
     def forward(self, x):
         if x.dim() != 2:
@@ -36,6 +46,11 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
         if self.training:
             if self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)
+            if self.sync_group is not False:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.sync_group) > 1:
+                    return ops.sync_batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                                   self.eps, self.momentum, self.fuse_relu, self.sync_group)
             return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                       self.eps, self.momentum, self.fuse_relu)
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):

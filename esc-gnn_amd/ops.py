@@ -217,6 +217,89 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, eps, momentum, rel
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, eps, momentum, relu)
 
 
+class _SyncBatchNormAct(Function):
+    """BatchNorm1d(train) whose batch statistics span all ranks of a process group (what makes graph-sharded
+    data parallelism reproduce the single-device forward).  Forward: local (n, mean, M2) from esc_bn_stats, one
+    all_gather of 2C+1 doubles, Chan merge, esc_bn_apply with the global statistics.  Backward: local column sums
+    (esc_bn_bwd_sums), one all-reduce of 2C floats, esc_bn_bwd_apply with sums / N_global.  The incoming gradient must
+    belong to ONE objective shared by the ranks (sum-form loss, `l1_loss(..., denom=1)` + `FlatBucket.all_reduce_sum`)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, group):
+        import torch.distributed as dist
+        _dev(x, gamma, beta)
+        _on(x.device, gamma, beta, running_mean, running_var)
+        x, ldx = _rows(x)
+        M, C = x.shape
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(nv.lib().esc_bn_scratch(C), dtype=torch.float32, device=dev)
+        s = nv.stream()
+        pack = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
+        pack[0] = M
+        if M > 1:
+            nv.call("esc_bn_stats", nv.ptr(x), ldx, M, C, float(eps), float(momentum), nv.ptr(mean), nv.ptr(invstd),
+                    None, None, None, None, None, None, nv.ptr(scratch), s)
+            pack[1:C + 1] = mean.double()
+            pack[C + 1:] = (1.0 / invstd.double().pow(2) - float(eps)).clamp_min(0.0) * M        # M2 = var * n
+        elif M == 1:
+            pack[1:C + 1] = x[0].double()
+        world = dist.get_world_size(group)
+        gathered = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(gathered, pack, group=group)
+        n, mu, m2 = gathered[0][0].clone(), gathered[0][1:C + 1].clone(), gathered[0][C + 1:].clone()
+        for g in gathered[1:]:                                   # Chan merge in rank order (identical on every rank)
+            nb, mub, m2b = g[0], g[1:C + 1], g[C + 1:]
+            tot = n + nb
+            delta = mub - mu
+            mu = mu + delta * (nb / tot)
+            m2 = m2 + m2b + delta * delta * (n * nb / tot)
+            n = tot
+        if float(n) <= 1:
+            raise ValueError("Expected more than 1 value per channel when training (over all ranks)")
+        var = m2 / n
+        mean = mu.float()
+        invstd = torch.rsqrt(var + float(eps)).float()
+        if running_mean is not None:
+            running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_((m2 / (n - 1)).float(), alpha=momentum)
+        y = torch.empty((M, C), dtype=torch.float32, device=dev)
+        if M > 0:
+            nv.call("esc_bn_apply", nv.ptr(x), ldx, M, C, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+                    int(relu), nv.ptr(y), C, s)
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        ctx.relu, ctx.scratch, ctx.group, ctx.n_global = int(relu), scratch, group, float(n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy, ldg = _rows(dy)
+        M, C = x.shape
+        dev = x.device
+        sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)
+        dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
+        dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
+        s = nv.stream()
+        if M > 0:
+            nv.call("esc_bn_bwd_sums", nv.ptr(x), x.stride(0), nv.ptr(y), C, nv.ptr(dy), ldg, M, C, nv.ptr(mean),
+                    nv.ptr(invstd), nv.ptr(gamma), None, int(ctx.relu), nv.ptr(sums), nv.ptr(dgamma), nv.ptr(dbeta),
+                    nv.ptr(ctx.scratch), s)
+        dist.all_reduce(sums, group=ctx.group)
+        coef = sums / ctx.n_global
+        dx = torch.empty((M, C), dtype=torch.float32, device=dev)
+        if M > 0:
+            nv.call("esc_bn_bwd_apply", nv.ptr(x), x.stride(0), nv.ptr(y), C, nv.ptr(dy), ldg, M, C, nv.ptr(mean),
+                    nv.ptr(invstd), nv.ptr(gamma), None, int(ctx.relu), nv.ptr(coef), nv.ptr(dx), C, s)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def sync_batch_norm_act(x, gamma, beta, running_mean, running_var, eps, momentum, relu, group=None):
+    return _SyncBatchNormAct.apply(x, gamma, beta, running_mean, running_var, eps, momentum, relu, group)
+
+
 def bn_eval_act(x, gamma, beta, running_mean, running_var, eps, relu):
     """Inference-mode BatchNorm (+ReLU) with running statistics — no autograd (eval/no_grad path)."""
     _dev(x)

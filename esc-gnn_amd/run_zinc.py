@@ -53,6 +53,8 @@ _FLAGS = [  # same names, types and defaults as the reference CLI
     ("--train_only", dict(default=0, type=int)),
     # additions (not in the reference): size of the synthetic stand-in for the absent ZINC.pkl
     ("--synthetic_graphs", dict(type=int, default=12000, help="train+val+test molecules (10:1:1 like ZINC-12k)")),
+    ("--sync_bn", dict(action="store_true", default=False,
+                       help="data parallel only: BatchNorm statistics over all ranks (single-device-equivalent numerics)")),
 ]
 
 
@@ -112,6 +114,9 @@ def main(argv=None):
         model.load_state_dict(torch.load(args.load_model, map_location="cpu"))
     ctx.say("Using " + model.__class__.__name__ + " model")
     model = model.to(ctx.device)
+    if args.sync_bn and ctx.world > 1:
+        from .nn import BatchNorm1d
+        BatchNorm1d.convert_sync(model)
     broadcast_parameters(model, 0)
     optimizer = FlatAdam(model.parameters(), lr=args.lr)
     scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=args.lr_decay_factor, patience=args.patience,
@@ -124,6 +129,12 @@ def main(argv=None):
         for data, n_global in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
             optimizer.zero_grad()
             y = data.y.view(-1, 1)
+            if ctx.world > 1 and args.sync_bn:            # one objective shared by the ranks: sum form, divided once
+                loss = ops.l1_loss(model(data), y, denom=1)
+                loss.backward()
+                loss_all += loss.detach()
+                optimizer.step(grad_denom=optimizer.all_reduce_sum(y.size(0)))
+                continue
             loss = ops.l1_loss(model(data), y)            # torch.nn.L1Loss (reference :290-291)
             loss.backward()
             if ctx.world > 1:

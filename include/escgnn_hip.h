@@ -196,6 +196,18 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
                int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
                const float* gamma, const float* beta, int relu, float* dX, int64_t ld_dx,
                float* dgamma, float* dbeta, float* scratch, void* stream);
+/* The two halves of esc_bn_bwd for a BatchNorm whose statistics span several ranks (SyncBN):
+ * _sums writes sums[c] = (sum g, sum g*xhat) over the LOCAL rows (float2[C]; g = dY * act'), with mean / invstd the
+ * GLOBAL statistics, plus the local dgamma / dbeta; the caller all-reduces `sums`, divides by the global row count
+ * and hands the result to _apply as `coef`. */
+int esc_bn_bwd_sums(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
+                    int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, int relu, float* sums, float* dgamma,
+                    float* dbeta, float* scratch, void* stream);
+int esc_bn_bwd_apply(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
+                     int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int relu, const float* coef, float* dX,
+                     int64_t ld_dx, void* stream);
 
 /* Y = relu?(X*scale + shift) — materialises a BatchNorm(+ReLU) output from its fused coefficients */
 int esc_affine_act(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* scale,

@@ -1,0 +1,84 @@
+"""SyncBN under graph-sharded data parallelism: two ranks, each with half of the graphs of a batch and
+BatchNorm statistics all-reduced over the ranks, reproduce the single-process forward and gradients of the full batch.
+Both ranks share the one GPU of the test box (gloo carries the collectives)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, require_gpu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup():
+    import esc_gnn_amd as E
+    from esc_gnn_amd.datasets import build_count_dataset
+    graphs = build_count_dataset(0, 12, h=2, use_rd=True, self_loop=True)
+    gen = torch.Generator().manual_seed(3)
+    for g in graphs:
+        g.x = torch.randn(g.x.shape, generator=gen)
+        g.y = torch.randn(g.x.size(0), generator=gen)
+    store = E.DeviceGraphStore(graphs, DEV)
+    torch.manual_seed(5)
+    model = E.NestedGIN_eff(None, 2, 32, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to(DEV)
+    return E, store, model
+
+
+def _worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E, store, model = _setup()
+    E.nn.BatchNorm1d.convert_sync(model)
+    model.train()
+    ids = torch.arange(12)
+    lo, hi = E.parallel.shard_slice(12, rank, world)
+    b = store.collate(ids[lo:hi])
+    n_glob = int(store.h_node_ptr[12])
+    pred = model(b)
+    loss = E.ops.l1_loss(pred, b.y, denom=n_glob)            # this rank's share of the global mean
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    dist.all_reduce(grads)
+    tot = loss.detach().clone()
+    dist.all_reduce(tot)
+    bufs = torch.cat([v.reshape(-1).float() for k, v in model.named_buffers() if "num_batches" not in k])
+    q.put((rank, pred.detach().cpu().numpy(), grads.cpu().numpy(), float(tot), bufs.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_syncbn_equals_full_batch():
+    require_gpu()
+    world, port = 2, 29600 + os.getpid() % 300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    E, store, model = _setup()
+    model.train()
+    b = store.collate(torch.arange(12))
+    pred = model(b)
+    loss = E.ops.l1_loss(pred, b.y)
+    loss.backward()
+    want_g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
+    want_b = torch.cat([v.reshape(-1).float() for k, v in model.named_buffers() if "num_batches" not in k]).cpu()
+    got_pred = torch.cat([torch.from_numpy(r[1]) for r in res])
+    assert torch.allclose(got_pred, pred.detach().cpu(), rtol=1e-5, atol=1e-5)
+    for r in res:
+        assert abs(r[3] - float(loss.detach())) <= 1e-5 * max(1.0, abs(float(loss.detach())))
+        g = torch.from_numpy(r[2])
+        assert float((g - want_g).norm()) <= 1e-4 * float(want_g.norm()) + 1e-6
+        assert float((g - want_g).abs().max()) <= 1e-4 * max(1.0, float(want_g.abs().max()))
+        assert torch.allclose(torch.from_numpy(r[4]), want_b, rtol=1e-5, atol=1e-5)
+    assert (res[0][2] == res[1][2]).all()
