@@ -75,6 +75,12 @@ def sharded_batches(store, batch_size, ctx, shuffle, generator=None):
     order = torch.randperm(G, generator=generator) if shuffle else torch.arange(G)
     for i in range(0, G, batch_size):
         ids = order[i:i + batch_size]
+        if ids.numel() < ctx.world:
+            # a remainder smaller than the rank count would leave some ranks without data while the others enter the
+            # step's collectives: training drops it (every rank alike), evaluation hands it to rank 0
+            if shuffle or ctx.rank != 0:
+                continue
+            yield store.collate(ids), ids.numel()
+            continue
         lo, hi = shard_slice(ids.numel(), ctx.rank, ctx.world)
-        if hi > lo:
-            yield store.collate(ids[lo:hi]), ids.numel()
+        yield store.collate(ids[lo:hi]), ids.numel()

@@ -234,9 +234,12 @@ def main(argv=None):
         order = torch.randperm(G, generator=gen) if shuffle else torch.arange(G)
         for i in range(0, G, args.batch_size):
             ids = order[i:i + args.batch_size]
+            if ids.numel() < world:       # fewer graphs than ranks: some ranks would miss the step's collectives —
+                if not shuffle and rank == 0:                        # training drops it, evaluation gives it to rank 0
+                    yield ids
+                continue
             lo, hi = shard_slice(ids.numel(), rank, world)           # shard the global batch by graph
-            if hi > lo:
-                yield ids[lo:hi]
+            yield ids[lo:hi]
 
     def batches(store, shuffle):
         for ids in shards(store, shuffle):
