@@ -744,13 +744,16 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
   g.b_vec = vec_ok(W, ld_w); g.c_slab = 0;
   const int splits = 1;
   int id = (N <= 32) ? 2 : (M >= 8192 ? g_knob[KNOB_FWD_BIG] : g_knob[KNOB_FWD_SMALL]);
-  if (col_stats && id >= 8) id = 4;          // in-workgroup split-K tiles keep partial sums per wave group
+  // node-sized rows with a long reduction (lin1: K = (L+1)*H): 152 workgroups would each walk 20 K-steps alone;
+  // the 32x32 tile whose 4 wave groups split every K-step puts 4x the waves on the chip (42 -> 32 us)
+  if (N > 32 && M < 8192 && K >= 1024 && id == 4) id = 8;
   if (bn && (M > FUSE_FINALIZE_MAX_ROWS || !last_block_finalize())) {     // edge-sized: hundreds of partials per column — a wide finalize launch is faster
     ESC_TRY_(linear_fwd_impl(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, nullptr, stream));
     return esc_bn_stats_from_partials(col_stats, M, N, bn->eps, bn->momentum, bn->mean, bn->invstd, bn->running_mean,
                                       bn->running_var, bn->gamma, bn->beta, bn->scale, bn->shift, stream);
   }
   if (bn) {
+    if (id >= 8) id = 4;                       // the fused finalize lives in the one-wave-group tiles only
     int bm, bn_cols, bk;
     tile_dims(id, &bm, &bn_cols, &bk);
     const int col_tiles = (int)cdiv(N, bn_cols);
