@@ -90,6 +90,7 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
     }
     sl += esc_linear_bwd_weight_scratch(N, H, H) + esc_linear_bwd_weight_scratch(N, H, C0) + 2 * 64;   // x_embedding
     sl += esc_linear_bwd_weight_scratch(N, H, y.W) + esc_linear_bwd_weight_scratch(N, 1, H) + 2 * 64;  // lin1, lin2
+    sl += esc_linear_bwd_weight_scratch(N, H, 1) + 64;      // lin1 is reduced as two column blocks with a job each
     y.slabs = a.take(sl);
   }
   y.total = a.off;
@@ -144,7 +145,7 @@ static int g_use_side_stream = 0;     // esc_engine_set_side_stream(); measured 
 // (152 workgroups on 256 CUs) leave idle.  One event per dependency, no host synchronisation.
 struct EdgeStream {
   hipStream_t stream = nullptr;
-  hipEvent_t z_ready = nullptr, joined = nullptr, e_ready[ESC_MAX_LAYERS] = {}, de_ready[ESC_MAX_LAYERS] = {},
+  hipEvent_t z_ready = nullptr, joined = nullptr, lin1_fork = nullptr, lin1_rest = nullptr, e_ready[ESC_MAX_LAYERS] = {}, de_ready[ESC_MAX_LAYERS] = {},
              agg_done[ESC_MAX_LAYERS] = {};
   bool ok = false;
 };
@@ -161,6 +162,8 @@ static EdgeStream& edge_stream() {
     bool good = hipStreamCreateWithPriority(&es.stream, hipStreamNonBlocking, g_edge_priority_low ? least : greatest) == hipSuccess;
     good = good && hipEventCreateWithFlags(&es.z_ready, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&es.joined, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&es.lin1_fork, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&es.lin1_rest, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l < ESC_MAX_LAYERS; ++l) {
       good = good && hipEventCreateWithFlags(&es.e_ready[l], hipEventDisableTiming) == hipSuccess;
       good = good && hipEventCreateWithFlags(&es.de_ready[l], hipEventDisableTiming) == hipSuccess;
@@ -366,7 +369,27 @@ static int backward(const Ctx& c, Pending* defer) {
   ESC_TRY(linear_backward(c, y.dpred, 1, y.Yl, H, y.bl.scale, y.bl.shift, m->lin2, N, y.dAl, H, 0));
   ESC_TRY(esc_bn_bwd(y.Yl, H, nullptr, 0, y.dAl, H, N, H, y.bl.mean, y.bl.invstd, m->bn_lin1.gamma, m->bn_lin1.beta, 1,
                      y.dAl, H, m->bn_lin1.dgamma, m->bn_lin1.dbeta, y.bn_scratch, c.s));
-  ESC_TRY(linear_backward(c, y.dAl, H, y.cat, W, nullptr, nullptr, m->lin1, N, y.dcat, W, 0));
+  // lin1 backward.  The node chain needs d(cat)[:, L*H:] (the last layer's output gradient) at once and the other
+  // slices only when the first aggregate backward accumulates into them ~60 us later: with an edge stream the last
+  // column block (dX slice + its dW columns) is computed here and the other L blocks over there, concurrently.
+  EdgeStream& es = edge_stream();
+  const bool split_lin1 = es.ok && c.jobs != nullptr && L >= 1;
+  if (split_lin1) {
+    const int64_t K0 = L * H;                                 // columns [0, K0) go to the edge stream
+    auto part = [&](void* stream, int64_t col0, int64_t ncols, float* db) -> int {
+      float* slabs = *c.slab_cursor;
+      *c.slab_cursor += (esc_linear_bwd_weight_scratch(N, H, ncols) + 63) & ~63LL;
+      c.jobs->emplace_back();
+      return esc_linear_bwd_both_deferred(y.dAl, H, y.cat + col0, W, nullptr, nullptr, m->lin1.w + col0, W, N, H, ncols,
+                                          y.dcat + col0, W, 0, m->lin1.dw + col0, W, db, slabs, &c.jobs->back(), stream);
+    };
+    ESC_TRY(chain(es.lin1_fork, (hipStream_t)c.s, es.stream));
+    ESC_TRY(part(es.stream, 0, K0, nullptr));
+    if (hipEventRecord(es.lin1_rest, es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+    ESC_TRY(part(c.s, K0, H, m->lin1.db));
+  } else {
+    ESC_TRY(linear_backward(c, y.dAl, H, y.cat, W, nullptr, nullptr, m->lin1, N, y.dcat, W, 0));
+  }
   // x_embedding backward (input x needs no gradient): only reads d(cat)[:, 0:H] -> side stream
   SideStream& ss = side_stream();
   if (ss.ok) {
@@ -374,12 +397,15 @@ static int backward(const Ctx& c, Pending* defer) {
       set_error("esc_engine: side-stream fork failed");
       return ESC_ELAUNCH;
     }
+    if (split_lin1 && hipStreamWaitEvent(ss.stream, es.lin1_rest, 0) != hipSuccess) {      // d(cat)[:, 0:H] comes from there
+      set_error("esc_engine: stream event failed");
+      return ESC_ELAUNCH;
+    }
     const Ctx cx = side_ctx(c, ss.stream);
     ESC_TRY(mlp_backward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
     (void)hipEventRecord(ss.join_b, ss.stream);
   }
   // GINE layers, last to first (the eps gradients are only needed by the optimiser: one reduce launch at the end)
-  EdgeStream& es = edge_stream();
   Ctx ce = es.ok ? edge_ctx(c, es.stream) : c;
   std::vector<esc_reduce_job> edge_jobs;     // the edge pipeline's weight gradients are reduced after the join,
   edge_jobs.reserve(ESC_MAX_REDUCE_JOBS);    // the node pipeline's while the edge tail is still running
@@ -393,6 +419,8 @@ static int backward(const Ctx& c, Pending* defer) {
     ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W,
                          y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C));
     float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
+    if (split_lin1 && l == (int)L - 1 &&                               // ... which the edge stream's lin1 blocks fill
+        hipStreamWaitEvent((hipStream_t)c.s, es.lin1_rest, 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
                                    y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
@@ -498,7 +526,7 @@ static int train_step_impl(const esc_nested_gin_t* m, const esc_batch_t* b, floa
   std::vector<esc_reduce_job> jobs;
   jobs.reserve(ESC_MAX_REDUCE_JOBS);
   float* cursor = c.y.slabs;
-  if (3 * m->num_layers + 6 <= ESC_MAX_REDUCE_JOBS) { c.jobs = &jobs; c.slab_cursor = &cursor; }
+  if (3 * m->num_layers + 7 <= ESC_MAX_REDUCE_JOBS) { c.jobs = &jobs; c.slab_cursor = &cursor; }
   ESC_TRY(forward(c));
   ESC_TRY(esc_l1_loss(c.y.pred, b->y, b->N, loss_denom > 0 ? loss_denom : b->N, 1.0f, loss, c.y.dpred, stream));
   if (pred) {
