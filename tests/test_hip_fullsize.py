@@ -251,3 +251,35 @@ def test_split_step_equals_single_call(E, world):
     for (name, p), g in zip(eng.model.named_parameters(), g1):
         assert torch.equal(p.grad, g), name
     assert bool(torch.isfinite(pred).all())
+
+
+@pytest.mark.parametrize("L,H,bs", [(1, 32, 3), (2, 64, 17), (5, 256, 40), (3, 128, 2)])
+def test_engine_matches_autograd_over_shapes(E, L, H, bs):
+    """The two-stream engine against the per-op autograd path over layer counts / widths / batch sizes the fixed
+    BASELINE shapes do not exercise (L=1: no hidden GINE layer; L=5: the reference's default depth; tiny batches)."""
+    from esc_gnn_amd.datasets import build_count_dataset
+    import copy
+    graphs = build_count_dataset(100, bs, h=3, use_rd=True, self_loop=True)
+    gen = torch.Generator().manual_seed(L * 100 + bs)
+    for g in graphs:
+        g.x = torch.randn(g.x.shape, generator=gen)
+        g.y = torch.randn(g.x.size(0), generator=gen)
+    store = E.DeviceGraphStore(graphs, DEV)
+    b = store.collate(torch.arange(bs))
+    torch.manual_seed(L + H)
+    m = E.NestedGIN_eff(None, L, H, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to(DEV)
+    twin = copy.deepcopy(m)
+    m.train(); twin.train()
+    eng = E.StepEngine(m)
+    for _ in range(2):                                           # twice: event / scratch reuse across steps
+        loss, pred = eng.train_step(b, return_pred=True)
+    twin.zero_grad()
+    pt = twin(b)
+    lt = E.ops.l1_loss(pt, b.y)
+    lt.backward()
+    assert torch.allclose(pred, pt.detach(), rtol=1e-5, atol=1e-5)
+    assert abs(float(loss) - float(lt.detach())) <= 1e-5 * max(1.0, abs(float(lt.detach())))
+    tw = dict(twin.named_parameters())
+    for n, p in m.named_parameters():
+        g = tw[n].grad
+        assert float((p.grad - g).norm()) <= 2e-4 * float(g.norm()) + 1e-6, n
