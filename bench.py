@@ -110,6 +110,8 @@ def main():
     opt = E.optim.FlatAdam(model.parameters(), lr=args.lr)
     model.train()
     engine = E.StepEngine(model) if args.path == "engine" else None
+    if engine is None:
+        model.engine_forward = False                       # --path autograd measures the per-op path
 
     stats = dict(graphs=0, nodes=0, edges=0, nnz=0)
 

@@ -75,6 +75,8 @@ SIGNATURES = {
     "esc_engine_train_step": [P, P, P, I64, P, P, P],
     "esc_engine_train_step_begin": [P, P, P, I64, P, P, P],
     "esc_engine_train_step_end": [],
+    "esc_engine_forward_train": [P, P, P, P, P],
+    "esc_engine_backward": [P, P, P, P, P],
     "esc_engine_predict": [P, P, P, P, P],
     "esc_l1_loss": [P, P, I64, I64, F32, P, P, P],
     "esc_bce_logits_loss": [P, P, I64, I64, P, P, P],

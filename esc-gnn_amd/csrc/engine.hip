@@ -461,12 +461,12 @@ static int backward(const Ctx& c, Pending* defer) {
   return ESC_OK;
 }
 
-static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* ws, bool train) {
+static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* ws, bool train, bool need_y = true) {
   ESC_REQUIRE(m && b && ws, "esc_engine: null pointer");
   ESC_REQUIRE(m->num_layers >= 1 && m->num_layers <= ESC_MAX_LAYERS, "esc_engine: %ld layers unsupported", (long)m->num_layers);
   ESC_REQUIRE(m->hidden > 0 && m->hidden % 4 == 0 && m->in_dim > 0, "esc_engine: hidden must be a multiple of 4");
   ESC_REQUIRE(b->N >= 2 && b->E >= 2 && b->Z >= 0, "esc_engine: batch needs >= 2 nodes and edges (BatchNorm statistics)");
-  ESC_REQUIRE(b->x && b->in_ptr && b->row_ptr && (!train || (b->y && b->out_ptr && b->col_ptr)), "esc_engine: null batch arrays");
+  ESC_REQUIRE(b->x && b->in_ptr && b->row_ptr && (!train || ((b->y || !need_y) && b->out_ptr && b->col_ptr)), "esc_engine: null batch arrays");
   ESC_REQUIRE(aligned16(ws), "esc_engine: workspace must be 16-byte aligned");
   return ESC_OK;
 }
@@ -536,6 +536,45 @@ static int train_step_impl(const esc_nested_gin_t* m, const esc_batch_t* b, floa
     }
   }
   return backward(c, defer);
+}
+
+// The step as an autograd node: forward in training mode (batch statistics, activations kept in `workspace`), then —
+// with the gradient of ANY loss w.r.t. the predictions — the backward.  The workspace must be left untouched in
+// between.  This is what lets `NestedGIN_eff.forward` itself run on the engine inside a user's own training loop.
+int esc_engine_forward_train(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
+                             void* stream) {
+  ESC_TRY(finish_pending(pending()));
+  int rc = check(m, b, workspace, true, false);
+  if (rc) return rc;
+  ESC_REQUIRE(pred, "esc_engine_forward_train: null output");
+  Ctx c{m, b, plan_layout(m, b->N, b->E, b->Z, workspace, true), stream, true};
+  std::vector<esc_reduce_job> jobs;            // only marks the main chain (statistics from the GEMM epilogues)
+  float* cursor = c.y.slabs;
+  c.jobs = &jobs; c.slab_cursor = &cursor;
+  ESC_TRY(forward(c));
+  if (hipMemcpyAsync(pred, c.y.pred, sizeof(float) * (size_t)b->N, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    set_error("esc_engine_forward_train: prediction copy failed");
+    return ESC_ELAUNCH;
+  }
+  return ESC_OK;
+}
+
+int esc_engine_backward(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, const float* dpred,
+                        void* stream) {
+  ESC_TRY(finish_pending(pending()));
+  int rc = check(m, b, workspace, true, false);
+  if (rc) return rc;
+  ESC_REQUIRE(dpred, "esc_engine_backward: null gradient");
+  Ctx c{m, b, plan_layout(m, b->N, b->E, b->Z, workspace, true), stream, true};
+  std::vector<esc_reduce_job> jobs;
+  jobs.reserve(ESC_MAX_REDUCE_JOBS);
+  float* cursor = c.y.slabs;
+  if (3 * m->num_layers + 7 <= ESC_MAX_REDUCE_JOBS) { c.jobs = &jobs; c.slab_cursor = &cursor; }
+  if (hipMemcpyAsync(c.y.dpred, dpred, sizeof(float) * (size_t)b->N, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    set_error("esc_engine_backward: gradient copy failed");
+    return ESC_ELAUNCH;
+  }
+  return backward(c, nullptr);
 }
 
 int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,

@@ -54,27 +54,57 @@ def _grad_ptr(p):
     return p.grad.data_ptr()
 
 
-def _lin(mod):
+def _lin(mod, gp=_grad_ptr):
     s = _Linear()
-    s.w, s.dw = mod.weight.data_ptr(), _grad_ptr(mod.weight)
-    s.b, s.db = (mod.bias.data_ptr(), _grad_ptr(mod.bias)) if mod.bias is not None else (None, None)
+    s.w, s.dw = mod.weight.data_ptr(), gp(mod.weight)
+    s.b, s.db = (mod.bias.data_ptr(), gp(mod.bias)) if mod.bias is not None else (None, None)
     s.in_dim, s.out_dim = mod.in_features, mod.out_features
     return s
 
 
-def _bn(mod):
+def _bn(mod, gp=_grad_ptr):
     s = _BN()
     s.gamma, s.beta = mod.weight.data_ptr(), mod.bias.data_ptr()
-    s.dgamma, s.dbeta = _grad_ptr(mod.weight), _grad_ptr(mod.bias)
+    s.dgamma, s.dbeta = gp(mod.weight), gp(mod.bias)
     s.running_mean, s.running_var = mod.running_mean.data_ptr(), mod.running_var.data_ptr()
     s.eps, s.momentum = mod.eps, mod.momentum
     return s
 
 
-def _mlp(seq):            # Sequential(Linear, Dropout, BN, ReLU, Linear, Dropout, BN, ReLU)
+def _mlp(seq, gp=_grad_ptr):            # Sequential(Linear, Dropout, BN, ReLU, Linear, Dropout, BN, ReLU)
     s = _MLP()
-    s.lin0, s.bn0, s.lin1, s.bn1 = _lin(seq[0]), _bn(seq[2]), _lin(seq[4]), _bn(seq[6])
+    s.lin0, s.bn0, s.lin1, s.bn1 = _lin(seq[0], gp), _bn(seq[2], gp), _lin(seq[4], gp), _bn(seq[6], gp)
     return s
+
+
+def describe(m, gp=_grad_ptr):
+    """esc_nested_gin_t of a NestedGIN_eff module; `gp(parameter)` names the address its gradient is written to."""
+    d = _Model()
+    convs = [m.conv1] + list(m.convs)
+    if len(convs) > MAX_LAYERS:
+        raise ValueError("at most %d layers" % MAX_LAYERS)
+    d.num_layers, d.hidden = len(convs), m.lin2.in_features
+    d.in_dim, d.z_rows = m.x_embedding[0].in_features, m.z_initial.num_embeddings
+    d.z_table, d.dz_table = m.z_initial.weight.data_ptr(), gp(m.z_initial.weight)
+    d.zbn0, d.zlin, d.zbn1 = _bn(m.z_embedding[1], gp), _lin(m.z_embedding[3], gp), _bn(m.z_embedding[5], gp)
+    d.xemb = _mlp(m.x_embedding, gp)
+    for i, cv in enumerate(convs):
+        c = _Conv()
+        c.eps, c.deps = cv.eps.data_ptr(), gp(cv.eps)
+        c.nn, c.lin = _mlp(cv.nn, gp), _lin(cv.lin, gp)
+        d.conv[i] = c
+    d.lin1, d.bn_lin1, d.lin2 = _lin(m.lin1, gp), _bn(m.bn_lin1, gp), _lin(m.lin2, gp)
+    return d
+
+
+def engine_supports(m):
+    """The configuration the whole-step engine covers: the run_graphcount one (reference :465)."""
+    if m.graph_pred or m.dropout != 0 or not m.use_cycle or m.lin1.weight.device.type != "cuda":
+        return False
+    if m.lin2.out_features != 1 or m.lin2.in_features % 4 != 0:
+        return False
+    # BatchNorm statistics over several ranks (SyncBN) need collectives between the layers: per-op path only
+    return all(getattr(mod, "sync_group", False) is False for mod in m.modules())
 
 
 class StepEngine(object):
@@ -93,27 +123,13 @@ class StepEngine(object):
     def refresh(self):
         """(Re)read parameter / gradient / buffer addresses — call after the optimiser re-homed them."""
         m = self.model
-        d = _Model()
-        convs = [m.conv1] + list(m.convs)
-        if len(convs) > MAX_LAYERS:
-            raise ValueError("at most %d layers" % MAX_LAYERS)
-        d.num_layers, d.hidden = len(convs), m.lin2.in_features
-        d.in_dim, d.z_rows = m.x_embedding[0].in_features, m.z_initial.num_embeddings
-        d.z_table, d.dz_table = m.z_initial.weight.data_ptr(), _grad_ptr(m.z_initial.weight)
-        d.zbn0, d.zlin, d.zbn1 = _bn(m.z_embedding[1]), _lin(m.z_embedding[3]), _bn(m.z_embedding[5])
-        d.xemb = _mlp(m.x_embedding)
-        for i, cv in enumerate(convs):
-            c = _Conv()
-            c.eps, c.deps = cv.eps.data_ptr(), _grad_ptr(cv.eps)
-            c.nn, c.lin = _mlp(cv.nn), _lin(cv.lin)
-            d.conv[i] = c
-        d.lin1, d.bn_lin1, d.lin2 = _lin(m.lin1), _bn(m.bn_lin1), _lin(m.lin2)
+        d = describe(m)
         self._desc = d
         self._keep = [p for p in m.parameters()]
         self._open = None
 
     def _batch(self, data, need_y):
-        dev = self.model.lin1.weight.device
+        dev = (self.model if isinstance(self, StepEngine) else self).lin1.weight.device
         if data.x.device != dev:
             data.to(dev)
         plan = plan_of(data)
@@ -174,3 +190,87 @@ class StepEngine(object):
         nv.call("esc_engine_predict", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(),
                 nv.stream())
         return pred.view(-1, 1)
+
+
+class _NodeCache(object):
+    """Per-model host-side cache of the autograd node: the parameter list, the BatchNorm step counters and a template of
+    the model descriptor with the positions of its gradient pointers, so that a step costs two small numpy patches
+    instead of two descriptor builds (~0.5 ms of Python)."""
+
+    MARK = 0x5E5C00000000
+
+    def __init__(self, model):
+        import numpy as np
+        self.params = list(model.parameters())
+        self.key = tuple(p.data_ptr() for p in self.params)
+        self.counters = [m.num_batches_tracked for m in model.modules()
+                         if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
+        index = {id(p): i for i, p in enumerate(self.params)}
+        self.template = describe(model, lambda p: self.MARK + index[id(p)])
+        words = np.frombuffer(self.template, dtype=np.uint64)
+        hits = np.nonzero((words >= self.MARK) & (words < self.MARK + len(self.params)))[0]
+        self.slots = hits                                                  # word positions of the gradient pointers
+        self.slot_param = (words[hits] - self.MARK).astype(np.int64)      # ... and whose gradient each one is
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += -(-p.numel() // 16) * 16                             # 64-byte aligned slices of one flat buffer
+        self.offsets, self.total = offs, total
+        self.byte_offsets = np.asarray(offs, dtype=np.uint64)[self.slot_param] * np.uint64(4)
+
+    def valid(self):
+        return self.key == tuple(p.data_ptr() for p in self.params)
+
+    def descriptor(self, grad_base):
+        import numpy as np
+        d = _Model.from_buffer_copy(self.template)
+        np.frombuffer(d, dtype=np.uint64)[self.slots] = np.uint64(grad_base) + self.byte_offsets
+        return d
+
+
+def _node_cache(model):
+    c = model.__dict__.get("_esc_node_cache")
+    if c is None or not c.valid():
+        c = _NodeCache(model)
+        model.__dict__["_esc_node_cache"] = c
+    return c
+
+
+class _EngineNode(torch.autograd.Function):
+    """`model(batch)` of a training-mode NestedGIN_eff as ONE autograd node on the whole-step engine: forward =
+    esc_engine_forward_train, backward = esc_engine_backward with d(loss)/d(pred) of whatever loss the caller built.
+    The user's own loop (`loss = L1Loss()(model(data), y); loss.backward(); optimizer.step()`, reference
+    run_graphcount.py:494-505) then runs at engine speed instead of one autograd node per op."""
+
+    @staticmethod
+    def forward(ctx, model, data, cache, *params):
+        dev = model.lin1.weight.device
+        b, keep = StepEngine._batch(model, data, False)            # (used unbound: only reads the module)
+        desc = cache.descriptor(0)                                 # the forward writes no gradient
+        need = nv.lib().esc_engine_workspace_floats(ctypes.byref(desc), b.N, b.E, b.Z)
+        ws = torch.empty(int(need), dtype=torch.float32, device=dev)   # private: stays intact until the backward
+        pred = torch.empty(b.N, dtype=torch.float32, device=dev)
+        nv.call("esc_engine_forward_train", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+        if cache.counters:
+            torch._foreach_add_(cache.counters, 1)
+        ctx.cache, ctx.b, ctx.keep, ctx.ws = cache, b, keep, ws
+        return pred.view(-1, 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dpred):
+        cache = ctx.cache
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
+        desc = cache.descriptor(flat.data_ptr())
+        g = dpred.reshape(-1)
+        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        nv.call("esc_engine_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+        grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
+                      for p, o in zip(cache.params, cache.offsets))
+        ctx.ws = ctx.keep = None
+        return (None, None, None) + grads
+
+
+def engine_forward(model, data):
+    cache = _node_cache(model)
+    return _EngineNode.apply(model, data, cache, *cache.params)

@@ -47,6 +47,7 @@ class NestedGIN_eff(torch.nn.Module):
         self.lin1 = Linear(num_layers * hidden + hidden, hidden)
         self.bn_lin1 = BatchNorm1d(hidden, eps=1e-5, momentum=0.1, fuse_relu=True)
         self.lin2 = Linear(hidden, 1 if use_cycle else dataset.num_classes)
+        self.engine_forward = True       # training-mode forward through the whole-step engine when it covers the config
 
     def reset_parameters(self):
         for layer in self.z_embedding.children():
@@ -62,6 +63,11 @@ class NestedGIN_eff(torch.nn.Module):
     def forward(self, data, return_embeddings=False):
         data.to(self.lin1.weight.device)
         x, edge_index, batch = data.x, data.edge_index, data.batch
+        if (self.training and torch.is_grad_enabled() and not return_embeddings and self.engine_forward
+                and "edge_pos" not in data and x.is_floating_point() and x.dim() == 2 and x.size(0) >= 2):
+            from .engine import engine_forward, engine_supports
+            if engine_supports(self) and x.size(1) == self.x_embedding[0].in_features:
+                return engine_forward(self, data)       # the whole step as one autograd node (engine.hip)
         plan = plan_of(data, Z_TABLE_ROWS)
         if "edge_pos" in data:                       # dense layout of the slow variant (reference :142-145)
             z = ops.linear(data.edge_pos.float(), self.z_initial.weight.t().contiguous())

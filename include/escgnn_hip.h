@@ -285,6 +285,13 @@ int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float
 int esc_engine_train_step_begin(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,
                                 int64_t loss_denom, float* loss, float* pred, void* stream);
 int esc_engine_train_step_end(void);
+/* The step as two autograd halves: forward in training mode (batch statistics; the activations stay in `workspace`,
+ * which must not be touched until the backward), and the backward from d(loss)/d(pred) of any loss (float[N]).
+ * Parameter gradients land where the model descriptor points, like esc_engine_train_step. */
+int esc_engine_forward_train(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
+                             void* stream);
+int esc_engine_backward(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, const float* dpred,
+                        void* stream);
 int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
                        void* stream);
 

@@ -138,6 +138,7 @@ def test_train_step_against_fp64_oracle_at_full_size(E, world):
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(DEV)
     twin = copy.deepcopy(mine)
+    twin.engine_forward = False                  # per-op autograd path: a second implementation of the same step
     cpu = {k: b[k].cpu() for k in ("x", "edge_index", "pos_enc", "pos_index", "pos_batch", "batch", "y")}
     ref.train()
     pr = ref(cpu["x"], cpu["edge_index"], cpu["pos_enc"], cpu["pos_index"], cpu["pos_batch"], cpu["batch"])
@@ -269,7 +270,9 @@ def test_engine_matches_autograd_over_shapes(E, L, H, bs):
     torch.manual_seed(L + H)
     m = E.NestedGIN_eff(None, L, H, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to(DEV)
     twin = copy.deepcopy(m)
-    m.train(); twin.train()
+    twin.engine_forward = False
+    node = copy.deepcopy(m)                                      # module forward as ONE autograd node on the engine
+    m.train(); twin.train(); node.train()
     eng = E.StepEngine(m)
     for _ in range(2):                                           # twice: event / scratch reuse across steps
         loss, pred = eng.train_step(b, return_pred=True)
@@ -283,3 +286,15 @@ def test_engine_matches_autograd_over_shapes(E, L, H, bs):
     for n, p in m.named_parameters():
         g = tw[n].grad
         assert float((p.grad - g).norm()) <= 2e-4 * float(g.norm()) + 1e-6, n
+    # the same step through `model(batch)` + a torch loss + autograd (the reference's own loop, run_graphcount.py:494-503)
+    for _ in range(2):
+        node.zero_grad(set_to_none=True)
+        pn = node(b)
+        assert pn.grad_fn is not None and type(pn.grad_fn).__name__.startswith("_EngineNode")
+        ln = torch.nn.L1Loss()(pn, b.y.view(-1, 1))
+        ln.backward()
+    assert torch.equal(pn.detach(), pred)
+    assert abs(float(ln.detach()) - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
+    for (n, p), (_, q) in zip(node.named_parameters(), m.named_parameters()):
+        assert float((p.grad - q.grad).norm()) <= 1e-5 * float(q.grad.norm()) + 1e-7, n
+    assert all(torch.equal(a, c) for a, c in zip(node.buffers(), m.buffers()))

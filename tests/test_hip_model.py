@@ -144,7 +144,8 @@ def test_step_engine_matches_oracle_and_autograd(L, H, tag):
     import copy
     E, ref, mine, b = _setup(L, H, tag, seed=3)
     ref.train(); mine.train()
-    twin = copy.deepcopy(mine)                            # autograd path on identical weights
+    twin = copy.deepcopy(mine)                            # per-op autograd path on identical weights
+    twin.engine_forward = False
     pr = ref(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
     lr = torch.nn.functional.l1_loss(pr, b["y"].view(-1, 1))
     lr.backward()

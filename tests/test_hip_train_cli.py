@@ -97,3 +97,34 @@ def test_ogb_cli_runs_checkpoints_and_ensemble(tmp_path, monkeypatch, capsys):
     ro.main((base + "--epochs 3 --continue_from 2").split())          # resume: trains epoch 3 only
     out = capsys.readouterr().out
     assert "epoch 3" in out and "epoch 2," not in out
+
+
+def test_reference_style_loop_with_torch_loss_and_optimizer():
+    """The loop of the reference (run_graphcount.py:494-505) verbatim — torch.nn.L1Loss, torch.optim.Adam,
+    optimizer.zero_grad / loss.backward / optimizer.step — on the drop-in module: the training-mode forward runs as one
+    autograd node on the whole-step engine, and it learns."""
+    require_gpu()
+    import esc_gnn_amd as E
+    from esc_gnn_amd.datasets import build_count_dataset
+    torch.manual_seed(0)
+    graphs = build_count_dataset(0, 64, h=3)
+    y = torch.cat([g.y for g in graphs]); mean, std = y.mean(), y.std()
+    for g in graphs:
+        g.y = (g.y - mean) / std
+    loader = E.DataLoader(graphs, batch_size=16, shuffle=False)            # host collate, like the reference
+    model = E.NestedGIN_eff(None, 3, 64, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to("cuda:0")
+    optimizer = torch.optim.Adam(model.parameters(), lr=5e-3)
+    losses = []
+    for epoch in range(10):
+        model.train()
+        for data in loader:
+            data = data.to("cuda:0")
+            optimizer.zero_grad()
+            yy = data.y.view([data.y.size(0), 1])
+            out = model(data)
+            assert type(out.grad_fn).__name__.startswith("_EngineNode")
+            loss = torch.nn.L1Loss()(out, yy)
+            loss.backward()
+            optimizer.step()
+            losses.append(float(loss.detach()))
+    assert sum(losses[-4:]) < 0.7 * sum(losses[:4]), losses
