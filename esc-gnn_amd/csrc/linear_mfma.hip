@@ -680,6 +680,157 @@ static void tile_dims(int id, int* bm, int* bn, int* bk) {
 
 static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (ld % 4 == 0); }
 
+// =================================================================================================
+// Narrow-output linears (N <= 4 output features, K <= 256): lin2 (H -> 1).  On the 128x32 MFMA tile this is 19
+// workgroups that pad N to 32 and crawl (17 us forward, 19 us backward in two launches vs 5 / 8 us here); they are
+// really bandwidth problems — X is read once — so: one wave per row batch, a lane owns one k-quad, the N weight
+// rows sit in registers, dot products by wave reduction.  Backward: dX rows and the workgroup's share of dW / db in
+// one pass; the shares are summed by the ordinary slab-reduce job (deterministic, one share per 128 rows).
+// =================================================================================================
+constexpr int NARROW_N = 4, NARROW_K = 256, NARROW_ROWS = 128;   // measured: at N = 10 the wave reductions cost more than the padded MFMA tile
+
+template <int NMAX, bool PRO>
+__global__ __launch_bounds__(256) void linear_narrow_fwd(const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         int M, int N, int K, float* __restrict__ Y, int64_t ldy) {
+  const int lane = lane_id();
+  const int k = lane * 4;
+  const bool valid = k < K;
+  float4 w[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+    w[n] = (valid && n < N) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), ph = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRO) {
+    if (valid) { ps = *reinterpret_cast<const float4*>(sc + k); ph = *reinterpret_cast<const float4*>(sh + k); }
+  }
+  const float bv = (bias != nullptr && lane < N) ? bias[lane] : 0.f;
+  const int stride = gridDim.x * 4;
+  for (int r0 = blockIdx.x * 4 + (threadIdx.x >> 6); r0 < M; r0 += 4 * stride) {
+    float4 x[4];                                   // 4 rows in flight per wave
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * stride;
+      x[u] = (valid && r < M) ? *reinterpret_cast<const float4*>(X + (size_t)r * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * stride;
+      if (r >= M) break;                           // wave-uniform
+      float4 v = x[u];
+      if constexpr (PRO) {
+        v = valid ? make_float4(fmaxf(fmaf(v.x, ps.x, ph.x), 0.f), fmaxf(fmaf(v.y, ps.y, ph.y), 0.f),
+                                fmaxf(fmaf(v.z, ps.z, ph.z), 0.f), fmaxf(fmaf(v.w, ps.w, ph.w), 0.f))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n) {
+        if (n < N) {                               // wave-uniform
+          const float p = wave_sum(v.x * w[n].x + v.y * w[n].y + v.z * w[n].z + v.w * w[n].w);
+          mine = (lane == n) ? p : mine;
+        }
+      }
+      if (lane < N) Y[(size_t)r * ldy + lane] = mine + bv;
+    }
+  }
+}
+
+template <int NMAX, bool PRO>
+__global__ __launch_bounds__(256) void linear_narrow_bwd(const float* __restrict__ dY, int64_t lddy,
+                                                         const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         int M, int N, int K, float* __restrict__ dX, int64_t lddx,
+                                                         int accumulate, float* __restrict__ slab,
+                                                         float* __restrict__ db_part) {
+  __shared__ float4 red[3][64];
+  __shared__ float redb[3][NMAX];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int k = lane * 4;
+  const bool valid = k < K;
+  float4 w[NMAX], acc[NMAX];
+  float dbacc[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    w[n] = (valid && n < N) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dbacc[n] = 0.f;
+  }
+  float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), ph = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRO) {
+    if (valid) { ps = *reinterpret_cast<const float4*>(sc + k); ph = *reinterpret_cast<const float4*>(sh + k); }
+  }
+  const int row_end = min(M, (int)(blockIdx.x + 1) * NARROW_ROWS);
+  for (int r0 = blockIdx.x * NARROW_ROWS + wave; r0 < row_end; r0 += 16) {     // 4 rows in flight per wave
+    float4 x[4], old[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * 4;
+      const bool live = valid && r < row_end;
+      x[u] = live ? *reinterpret_cast<const float4*>(X + (size_t)r * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old[u] = (live && dX != nullptr && accumulate) ? *reinterpret_cast<const float4*>(dX + (size_t)r * lddx + k)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * 4;
+      if (r >= row_end) break;                     // wave-uniform
+      float4 v = x[u];
+      if constexpr (PRO) {
+        v = valid ? make_float4(fmaxf(fmaf(v.x, ps.x, ph.x), 0.f), fmaxf(fmaf(v.y, ps.y, ph.y), 0.f),
+                                fmaxf(fmaf(v.z, ps.z, ph.z), 0.f), fmaxf(fmaf(v.w, ps.w, ph.w), 0.f))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float4 d = old[u];
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n) {
+        if (n < N) {
+          const float g = dY[(size_t)r * lddy + n];              // same address in every lane: one broadcast load
+          d.x = fmaf(g, w[n].x, d.x); d.y = fmaf(g, w[n].y, d.y); d.z = fmaf(g, w[n].z, d.z); d.w = fmaf(g, w[n].w, d.w);
+          acc[n].x = fmaf(g, v.x, acc[n].x); acc[n].y = fmaf(g, v.y, acc[n].y);
+          acc[n].z = fmaf(g, v.z, acc[n].z); acc[n].w = fmaf(g, v.w, acc[n].w);
+          dbacc[n] += g;
+        }
+      }
+      if (valid && dX != nullptr) *reinterpret_cast<float4*>(dX + (size_t)r * lddx + k) = d;
+    }
+  }
+  // the four waves' shares, added in wave order, become this workgroup's slab
+  float* out = slab + (size_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    if (n >= N) break;
+    if (wave > 0) red[wave - 1][lane] = acc[n];
+    __syncthreads();
+    if (wave == 0 && valid) {
+      float4 t = acc[n];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { const float4 o = red[q][lane]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      *reinterpret_cast<float4*>(out + (size_t)n * K + k) = t;
+    }
+    __syncthreads();
+  }
+  if (wave > 0 && lane == 0) {
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) redb[wave - 1][n] = dbacc[n];
+  }
+  __syncthreads();
+  if (wave == 0 && lane == 0) {
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+      if (n < N) db_part[(size_t)blockIdx.x * N + n] = ((dbacc[n] + redb[0][n]) + redb[1][n]) + redb[2][n];
+  }
+}
+
+static inline bool narrow_ok(int64_t N, int64_t K, const float* X, int64_t ld_x, const float* W, int64_t ld_w,
+                             const float* sc, const float* sh) {
+  return N <= NARROW_N && K <= NARROW_K && K % 4 == 0 && vec_ok(X, ld_x) && vec_ok(W, ld_w) &&
+         (sc == nullptr || (aligned16(sc) && aligned16(sh)));
+}
+
 // tuning knobs (esc_tune_set): defaults chosen from scratch/gemm_bench.py sweeps on MI355X
 enum { KNOB_FWD_BIG = 0, KNOB_FWD_SMALL = 1, KNOB_DX_BIG = 2, KNOB_DX_SMALL = 3, KNOB_DW_TILE = 4,
        KNOB_DW_BLOCKS = 5, KNOB_DW_MIN_ROWS = 6, KNOB_DUAL_SMALL = 7, KNOB_COUNT = 8 };
@@ -735,6 +886,16 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
   ESC_REQUIRE(bn == nullptr || ((bn->scale == nullptr) == (bn->shift == nullptr)), "esc_linear_bn_fwd: scale/shift must come together");
   if (M == 0) return ESC_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (col_stats == nullptr && narrow_ok(N, K, X, ld_x, W, ld_w, in_scale, in_shift)) {
+    const unsigned blocks = (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048);      // 4 rows per wave and pass
+#define ESC_NARROW_FWD(NM) \
+    if (in_scale) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y); \
+    else          esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, false>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y)
+    if (N == 1) { ESC_NARROW_FWD(1); } else { ESC_NARROW_FWD(4); }
+#undef ESC_NARROW_FWD
+    ESC_CHECK_LAUNCH("esc_linear_fwd.narrow");
+    return ESC_OK;
+  }
   GemmArgs g{};
   g.A = X; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.C = Y; g.ldc = ld_y; g.bias = bias;
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.db_part = nullptr;
@@ -945,7 +1106,27 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
                      float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw, float* db,
                      float* slabs, esc_reduce_job* defer, void* stream) {
   ESC_REQUIRE(dY && X && W && dW && slabs, "esc_linear_bwd_both: null pointer");
-  if (dX == nullptr || N <= 32 || K <= 32) {             // narrow shapes keep their dedicated tiles
+  if (M > 0 && M < (1LL << 31) && ld_dy >= N && ld_dw >= K && (dX == nullptr || (vec_ok(dX, ld_dx) && ld_dx >= K)) &&
+      aligned16(slabs) && narrow_ok(N, K, X, ld_x, W, ld_w, in_scale, in_shift) &&
+      (in_scale == nullptr) == (in_shift == nullptr)) {
+    // dX rows and the dW / db shares in one pass over X and dY (see linear_narrow_bwd)
+    hipStream_t s = (hipStream_t)stream;
+    const int splits = (int)cdiv(M, NARROW_ROWS);
+    float* db_part = slabs + (size_t)splits * N * K;
+#define ESC_NARROW_BWD(NM) \
+    if (in_scale) esc::launch(ESC_K_LINEAR, linear_narrow_bwd<NM, true>, dim3(splits), dim3(256), 0, s, dY, ld_dy, X, ld_x, W, ld_w, in_scale, in_shift, (int)M, (int)N, (int)K, dX, ld_dx, accumulate, slabs, db_part); \
+    else          esc::launch(ESC_K_LINEAR, linear_narrow_bwd<NM, false>, dim3(splits), dim3(256), 0, s, dY, ld_dy, X, ld_x, W, ld_w, in_scale, in_shift, (int)M, (int)N, (int)K, dX, ld_dx, accumulate, slabs, db_part)
+    if (N == 1) { ESC_NARROW_BWD(1); } else { ESC_NARROW_BWD(4); }
+#undef ESC_NARROW_BWD
+    ESC_CHECK_LAUNCH("esc_linear_bwd_both.narrow");
+    const int64_t n = N * K;
+    if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, db_part, N, db); return ESC_OK; }
+    esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+                splits, (int)K, dW, ld_dw, db_part, (int)N, db);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_both.narrow_reduce");
+    return ESC_OK;
+  }
+  if (dX == nullptr || N <= 32 || K <= 32) {             // other narrow shapes keep their dedicated tiles
     int rc = weight_impl(dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, dW, ld_dw, db, slabs, defer, stream);
     if (rc || dX == nullptr) return rc;
     return esc_linear_bwd_input(dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate, stream);
