@@ -76,6 +76,12 @@ unsigned* tickets(int n);
 // Measured on MI355X (cfg1 step, r01): the fused tail costs what the finalize launch did — the last workgroup pays
 // an atomic round trip, an L2 invalidate and cold reads of partials that were written through to memory:
 // 1.712 ms with it vs 1.692 ms without.  Kept as an option (esc_tune_set(8, 1)), off by default.
+// Dynamic-LDS floor of the GEMM launches of the calling thread: the step engine can raise it around the edge stream's
+// GEMMs so that they occupy 3 instead of 4 workgroups per CU (esc_tune_set(10, bytes); 0 = off).
+int gemm_lds_floor();
+void set_gemm_lds_floor(int bytes);
+int edge_lds_floor();
+void set_edge_lds_floor(int bytes);
 int norm_rowblock_cap();              // workgroups per column block of the BatchNorm reduction kernels (esc_tune_set(9, v))
 void set_norm_rowblock_cap(int v);
 bool last_block_finalize();

@@ -111,11 +111,20 @@ struct Ctx {
   bool train;
   std::vector<esc_reduce_job>* jobs = nullptr;   // deferred weight-gradient reduces (main chain only)
   float** slab_cursor = nullptr;
+  bool on_edge_stream = false;
 };
 
 // dX + dW tiles now, slab reduce deferred (or immediate when the context has no job list)
+static int g_cap_forward = 0;     // esc_engine_set_side_stream bit 3: also cap the forward's edge GEMMs
+struct LdsFloorGuard {            // occupancy cap for the GEMMs launched while it lives (edge stream only)
+  explicit LdsFloorGuard(bool on) : on_(on && edge_lds_floor() > 0) { if (on_) set_gemm_lds_floor(edge_lds_floor()); }
+  ~LdsFloorGuard() { if (on_) set_gemm_lds_floor(0); }
+  bool on_;
+};
+
 static int linear_backward(const Ctx& c, const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* sc,
                            const float* sh, const esc_linear_t& lin, int64_t M, float* dX, int64_t ld_dx, int accumulate) {
+  const LdsFloorGuard cap(c.on_edge_stream);
   const int64_t N = lin.out_dim, K = lin.in_dim;
   if (c.jobs == nullptr)
     return esc_linear_bwd_both(dY, ld_dy, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db,
@@ -197,6 +206,7 @@ static SideStream& side_stream() {
 static Ctx edge_ctx(const Ctx& c, hipStream_t edge) {       // same job list / slab cursor: host-side bookkeeping only
   Ctx x = c;
   x.s = edge;
+  x.on_edge_stream = true;
   x.y.bn_scratch = c.y.bn_scratch_e;
   x.y.col_stats = c.y.col_stats_e;
   return x;
@@ -216,6 +226,7 @@ static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's
 // Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
 static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linear_t& lin, const float* sc, const float* sh,
                      int64_t M, float* Y, const esc_bn_t& bn, const BnWs& w) {
+  const LdsFloorGuard cap(c.on_edge_stream && g_cap_forward);
   const int64_t H = c.y.H, K = lin.in_dim;
   const bool fused = c.train && g_gemm_stats && H > 32 && c.jobs != nullptr;   // main chain only (col_stats is shared scratch)
   if (fused && g_fuse_finalize && M > 1) {    // statistics AND their merge ride on the GEMM launch
@@ -289,6 +300,7 @@ static int forward(const Ctx& c) {
   // The edge terms run two layers ahead of the node chain: e_{l+2} is queued behind the aggregate of layer l, so that a
   // bandwidth-bound aggregate never shares the HBM with an edge-sized GEMM (both would only slow each other down).
   auto edge_term = [&](int l) -> int {
+    const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
     const esc_conv_t& cv = m->conv[l];
     const int64_t C = l == 0 ? y.C0 : H;
     if (mat) ESC_TRY(esc_linear_fwd(y.Zemb, H, cv.lin.w, H, cv.lin.b, nullptr, nullptr, E, C, H, y.e[l], C, nullptr, ce.s));
@@ -384,7 +396,10 @@ static int backward(const Ctx& c, Pending* defer) {
                                           y.dcat + col0, W, 0, m->lin1.dw + col0, W, db, slabs, &c.jobs->back(), stream);
     };
     ESC_TRY(chain(es.lin1_fork, (hipStream_t)c.s, es.stream));
-    ESC_TRY(part(es.stream, 0, K0, nullptr));
+    {
+      const LdsFloorGuard cap(true);
+      ESC_TRY(part(es.stream, 0, K0, nullptr));
+    }
     if (hipEventRecord(es.lin1_rest, es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     ESC_TRY(part(c.s, K0, H, m->lin1.db));
   } else {
@@ -479,6 +494,7 @@ extern "C" {
 
 int esc_engine_set_side_stream(int on) {
   g_use_edge_stream = (on & 2) != 0;
+  g_cap_forward = (on & 8) != 0;
   g_edge_priority_low = (on & 4) == 0;      // bit 2: give the edge stream the HIGHEST priority instead (experiments)
   g_use_side_stream = (on & 1) != 0;
   return ESC_OK;

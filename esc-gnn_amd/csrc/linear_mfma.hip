@@ -643,7 +643,13 @@ static void launch_tile(const GemmArgs& g, int splits, hipStream_t s) {
     if (!raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
   }
   dim3 grid((unsigned)cdiv(g.colsC, BN), (unsigned)cdiv(g.rowsC, BM), (unsigned)splits);
-  esc::launch(ESC_K_LINEAR, kern, grid, dim3(NTHR), lds, s, g);
+  const size_t floor_ = (size_t)gemm_lds_floor();
+  const size_t use = lds > floor_ ? lds : floor_;
+  if (use > 64 * 1024 && use > lds) {
+    static size_t raised_to = 0;     // per instantiation
+    if (use > raised_to) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)use); raised_to = use; }
+  }
+  esc::launch(ESC_K_LINEAR, kern, grid, dim3(NTHR), use, s, g);
 }
 
 // tile shapes, selectable per call site (esc_tune_set) — ids are stable
@@ -872,7 +878,7 @@ static inline bool narrow_ok(int64_t N, int64_t K, const float* X, int64_t ld_x,
 // tuning knobs (esc_tune_set): defaults chosen from scratch/gemm_bench.py sweeps on MI355X
 enum { KNOB_FWD_BIG = 0, KNOB_FWD_SMALL = 1, KNOB_DX_BIG = 2, KNOB_DX_SMALL = 3, KNOB_DW_TILE = 4,
        KNOB_DW_BLOCKS = 5, KNOB_DW_MIN_ROWS = 6, KNOB_DUAL_SMALL = 7, KNOB_COUNT = 8 };
-static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128, 0};
+static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128, 2};
 
 }  // namespace esc
 
@@ -904,6 +910,7 @@ int esc_debug_gemm_occupancy(int tile_id) {
 int esc_tune_set(int knob, int value) {
   if (knob == 8) { set_last_block_finalize(value); return ESC_OK; }
   if (knob == 9) { set_norm_rowblock_cap(value); return ESC_OK; }
+  if (knob == 10) { set_edge_lds_floor(value); return ESC_OK; }
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
   g_knob[knob] = value;
   return ESC_OK;
@@ -1097,7 +1104,13 @@ static void launch_dual(const DualArgs& a, hipStream_t s) {
     if (!raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); raised = true; }
   }
   const unsigned blocks = (unsigned)(a.dx_nx * a.dx_ny + a.dw_nx * a.dw_ny * a.dw_nz);
-  esc::launch(ESC_K_LINEAR, kern, dim3(blocks), dim3(NTHR), need, s, a);
+  const size_t floor_ = (size_t)gemm_lds_floor();        // occupancy cap requested by the caller (see common.h)
+  const size_t use = need > floor_ ? need : floor_;
+  if (use > 64 * 1024 && use > need) {
+    static size_t raised_to = 0;
+    if (use > raised_to) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)use); raised_to = use; }
+  }
+  esc::launch(ESC_K_LINEAR, kern, dim3(blocks), dim3(NTHR), use, s, a);
 }
 
 extern "C" {
@@ -1183,8 +1196,8 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
   // edge-sized: 64x64xBK32 (4 workgroups/CU); node-sized: KNOB_DUAL_SMALL picks 64x64xBK64 (0) or the 2-wave
   // 32x64xBK32 tile (1) that doubles the workgroup count of these under-filled grids
   const int small_tile = g_knob[KNOB_DUAL_SMALL];
-  const int bm = (M >= 8192 || small_tile == 0) ? 64 : 32, bn = 64;
-  const int bk = (M >= 8192 || small_tile != 0) ? 32 : 64;
+  const int bm = (M >= 8192 || small_tile != 1) ? 64 : 32, bn = 64;
+  const int bk = (M >= 8192 || small_tile != 0) ? 32 : 64;         // knob 7: 0 64x64xBK64, 1 32x64xBK32, 2 64x64xBK32
   int splits, per;
   wgrad_plan_tile(M, N, K, bm, bn, bk, &splits, &per);
   DualArgs a{};

@@ -49,6 +49,13 @@ static int g_last_block = 0;
 bool last_block_finalize() { return g_last_block != 0; }
 void set_last_block_finalize(int on) { g_last_block = on != 0; }
 
+static thread_local int g_gemm_lds_floor = 0;
+int gemm_lds_floor() { return g_gemm_lds_floor; }
+void set_gemm_lds_floor(int bytes) { g_gemm_lds_floor = bytes < 0 ? 0 : (bytes > 160 * 1024 ? 160 * 1024 : bytes); }
+static int g_edge_lds_floor = 52 * 1024;      // 3 edge-GEMM workgroups per CU: a wave slot per SIMD stays free for the node stream
+int edge_lds_floor() { return g_edge_lds_floor; }
+void set_edge_lds_floor(int bytes) { g_edge_lds_floor = bytes < 0 ? 0 : bytes; }
+
 static int g_norm_rowblock_cap = 256;
 int norm_rowblock_cap() { return g_norm_rowblock_cap; }
 void set_norm_rowblock_cap(int v) { g_norm_rowblock_cap = v < 1 ? 1 : (v > 512 ? 512 : v); }

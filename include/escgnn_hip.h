@@ -127,12 +127,15 @@ int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w
                       float* Y, int64_t ld_y, float* col_stats, const esc_bn_fuse* bn, void* stream);
 /* tile-shape / split knobs of the three GEMM forms (benchmark sweeps; defaults are the tuned ones):
  * 0 fwd tile for M>=8192, 1 fwd tile for small M, 2/3 same for dX, 4 dW tile, 5 dW target workgroups,
- * 6 dW minimum reduction rows per split (>=128), 7 node-sized fused-backward tile (0: 64x64xBK64, 1: 32x64xBK32 2-wave).
+ * 6 dW minimum reduction rows per split (>=128), 7 node-sized fused-backward tile (0: 64x64xBK64, 1: 32x64xBK32 2-wave,
+ * 2 (default): 64x64xBK32 — 37 KB of LDS, so that it fits next to three edge-stream workgroups on a CU).
  * tile ids: 0 128x128xBK32, 1 64x64xBK32, 2 128x32xBK32, 3 128x64xBK32, 4 64x64xBK64, 5 32x64xBK32 (2 waves),
  * 6 32x32xBK32 (1 wave), 7 64x32xBK32 (2 waves).
  * knob 8 (default 0): 1 = node-sized BatchNorm reductions (esc_linear_bn_fwd, esc_bn_bwd) are finished by the last
  * workgroup of the producing launch instead of a finalize launch (measured 1 % slower on the cfg1 step).
- * knob 9 (default 256, 1..512): workgroups per 256-column block of the BatchNorm-backward reduction kernel. */
+ * knob 9 (default 256, 1..512): workgroups per 256-column block of the BatchNorm-backward reduction kernel.
+ * knob 10 (default 53248): dynamic-LDS floor in bytes of the GEMMs the step engine launches on its edge stream (caps them
+ * at 3 workgroups per CU so that the node stream's kernels find a free wave slot; 0 = no cap). */
 int esc_tune_set(int knob, int value);
 int esc_debug_gemm_occupancy(int tile_id);   /* resident workgroups/CU the runtime predicts (diagnostics) */
 /* dX[M,K] = dY[M,N] * W[N,K]  (accumulate!=0: dX += ...) */
@@ -264,7 +267,9 @@ typedef struct esc_batch_t {
   const int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
   const int32_t *row_ptr, *bag_idx, *bag_val, *col_ptr, *col_row, *col_val, *col_col;
 } esc_batch_t;
-/* bit 1 (default on): the edge-sized conv.lin GEMMs of all layers run on a second HIP stream, ordered against the
+/* (bit 3: apply the knob-10 occupancy cap to the forward's edge GEMMs too, default: backward only; bit 2: edge stream at the
+ * highest instead of the lowest priority — both for experiments.)
+ * bit 1 (default on): the edge-sized conv.lin GEMMs of all layers run on a second HIP stream, ordered against the
  * node chain by one event per dependency; bit 0 (default off): the x_embedding branch on a further stream.  Default 2. */
 int esc_engine_set_side_stream(int on);
 /* 1 (default): write relu(BN(.)) of the two EDGE-sized z_embedding activations once instead of re-applying the
