@@ -373,7 +373,10 @@ static int bag_bwd_impl(const float* dz, int64_t ld_dz, int64_t H, const int32_t
     const int64_t chunks = esc::cdiv(Z, esc::BAG_CH);
     const int64_t blocks = esc::cdiv(chunks, 4);
     if (bag_local_schedule(Z, H, rows)) {          // chunks bucketed by row eighth (see bag_bwd_classify)
-      if (!classified) ESC_REQUIRE(esc_bag_bwd_classify(c_row, Z, H, rows, partials, stream) == ESC_OK, "%s", esc_last_error());
+      if (!classified) {
+        const int rc = esc_bag_bwd_classify(c_row, Z, H, rows, partials, stream);
+        if (rc != ESC_OK) return rc;               // the message is already set
+      }
       int* order = reinterpret_cast<int*>(partials + 2 * chunks * H);
       int* bucket_cnt = order + 8 * chunks;
       const unsigned per_group = (unsigned)(esc::cdiv(esc::cdiv(chunks, 8) * 5 / 4 + 4, 4));   // 25 % slack; the kernel strides beyond
