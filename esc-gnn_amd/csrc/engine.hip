@@ -115,6 +115,7 @@ struct Ctx {
 };
 
 // dX + dW tiles now, slab reduce deferred (or immediate when the context has no job list)
+static int g_cap_tail = 0;        // bit 4: ... and the z_embedding GEMM of the backward tail
 static int g_cap_forward = 0;     // esc_engine_set_side_stream bit 3: also cap the forward's edge GEMMs
 struct LdsFloorGuard {            // occupancy cap for the GEMMs launched while it lives (edge stream only)
   explicit LdsFloorGuard(bool on) : on_(on && edge_lds_floor() > 0) { if (on_) set_gemm_lds_floor(edge_lds_floor()); }
@@ -452,8 +453,10 @@ static int backward(const Ctx& c, Pending* defer) {
   // (the ReLU mask is recomputed from the pre-BN value even when the activation was materialised: one array less to read)
   ESC_TRY(esc_bn_bwd(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma,
                      m->zbn1.beta, 1, y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, ce.y.bn_scratch, ce.s));
-  if (mat) ESC_TRY(linear_backward(ce, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
-  else     ESC_TRY(linear_backward(ce, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
+  Ctx ct = ce;
+  ct.on_edge_stream = ce.on_edge_stream && g_cap_tail;    // the tail is the critical path: its GEMM runs at full occupancy
+  if (mat) ESC_TRY(linear_backward(ct, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
+  else     ESC_TRY(linear_backward(ct, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
   ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, ce.y.bn_scratch, ce.s));
   ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E,
@@ -495,6 +498,7 @@ extern "C" {
 int esc_engine_set_side_stream(int on) {
   g_use_edge_stream = (on & 2) != 0;
   g_cap_forward = (on & 8) != 0;
+  g_cap_tail = (on & 16) != 0;
   g_edge_priority_low = (on & 4) == 0;      // bit 2: give the edge stream the HIGHEST priority instead (experiments)
   g_use_side_stream = (on & 1) != 0;
   return ESC_OK;
