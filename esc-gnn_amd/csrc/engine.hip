@@ -445,6 +445,10 @@ static int backward(const Ctx& c, Pending* defer) {
       ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Zemb, H, nullptr, nullptr, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
     else
       ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
+    if (es.ok && !edge_jobs.empty()) {      // the edge stream now idles until d_e of the next layer: reduce these slabs there
+      ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));
+      edge_jobs.clear();
+    }
   }
   if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
   // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order); it overlaps the
