@@ -267,8 +267,8 @@ typedef struct esc_batch_t {
   const int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
   const int32_t *row_ptr, *bag_idx, *bag_val, *col_ptr, *col_row, *col_val, *col_col;
 } esc_batch_t;
-/* (bit 3: apply the knob-10 occupancy cap to the forward's edge GEMMs too, default: backward only; bit 4: also to the
- * z_embedding GEMM of the backward tail; bit 2: edge stream at the
+/* (bit 3: do NOT apply the knob-10 occupancy cap to the forward's edge GEMMs; bit 4: apply it also to the z_embedding GEMM
+ * of the backward tail; bit 5: edge terms two layers ahead of the node chain instead of one; bit 2: edge stream at the
  * highest instead of the lowest priority — both for experiments.)
  * bit 1 (default on): the edge-sized conv.lin GEMMs of all layers run on a second HIP stream, ordered against the
  * node chain by one event per dependency; bit 0 (default off): the x_embedding branch on a further stream.  Default 2. */
