@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table at the BASELINE config-1 shapes (N=2400 nodes, E=15200 edges, Z≈5.5e5 histogram entries,
+H=256), each kernel launched back to back on a real collated batch and timed with the library's dispatch-event hook.
+
+    python tools/kernel_roofline.py > profiles/r01_kernel_roofline.txt          (on a GPU box)
+
+Algorithmic bytes / flops are the SURVEY §8(d) figures.  Back-to-back launches keep operands warm in
+L2 / Infinity Cache, so these are ceilings for the in-step numbers of profiles/r01_bench_kernel_stats.csv.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import esc_gnn_amd as E  # noqa: E402
+from esc_gnn_amd import _native as nv  # noqa: E402
+from esc_gnn_amd.datasets import build_count_dataset  # noqa: E402
+
+HBM, MFMA = 8000.0, 157.3
+dev = "cuda:0"
+
+
+def timed(kind, fn, n=60):
+    for _ in range(8):
+        fn()
+    torch.cuda.synchronize()
+    nv.prof_reset(kind)
+    nv.prof_enable(kind, True)
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    nv.prof_enable(kind, False)
+    launches, ms = nv.prof_read(kind)
+    return ms / n * 1e3, launches / n
+
+
+def main():
+    graphs = build_count_dataset(0, 256, h=3)
+    store = E.DeviceGraphStore(graphs, dev)
+    b = store.collate(torch.arange(128))
+    plan = E.plan_of(b)
+    N, Ee, Z, H = plan.num_nodes, plan.num_edges, plan.nnz, 256
+    s = nv.stream()
+    rows = []
+
+    def add(name, us, launches, nbytes=None, flops=None):
+        if nbytes is not None:
+            gbs = nbytes / us / 1e3
+            rows.append((name, "%.1f" % us, "%d" % launches, "%.1f MB" % (nbytes / 1e6), "%.0f GB/s" % gbs, "%.0f %% of HBM" % (100 * gbs / HBM)))
+        else:
+            tf = flops / us / 1e6
+            rows.append((name, "%.1f" % us, "%d" % launches, "%.2f GFLOP" % (flops / 1e9), "%.1f TFLOP/s" % tf, "%.0f %% of fp32 MFMA" % (100 * tf / MFMA)))
+
+    x = torch.randn(N, H, device=dev)
+    e = torch.randn(Ee, H, device=dev)
+    eps = torch.zeros(1, device=dev)
+    out = torch.empty(N, H, device=dev)
+    us, k = timed("agg_fwd", lambda: nv.call("esc_gine_aggregate_fwd", nv.ptr(x), H, nv.ptr(e), H, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge), nv.ptr(plan.in_src), nv.ptr(eps), N, H, nv.ptr(out), H, s))
+    add("aggregate forward (scatter-add)", us, k, 2 * Ee * H * 4 + 2 * N * H * 4 + Ee * 8 + (N + 1) * 4)
+    g = torch.randn(N, H, device=dev)
+    de = torch.empty(Ee, H, device=dev)
+    dx = torch.zeros(N, H, device=dev)
+    dp = torch.empty(N, device=dev)
+    us, k = timed("agg_bwd", lambda: nv.call("esc_gine_aggregate_bwd", nv.ptr(x), H, nv.ptr(e), H, nv.ptr(g), H, nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, H, nv.ptr(de), H, nv.ptr(dx), H, 1, nv.ptr(dp), s))
+    add("aggregate backward", us, k, 2 * Ee * H * 4 + 3 * N * H * 4 + Ee * 8)
+    table = torch.randn(1800, H, device=dev)
+    zb = torch.empty(Ee, H, device=dev)
+    us, k = timed("bag_fwd", lambda: nv.call("esc_bag_fwd", nv.ptr(table), H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx), nv.ptr(plan.bag_val), Ee, nv.ptr(zb), H, s))
+    add("bag forward (HBM bytes)", us, k, Z * 8 + (Ee + 1) * 4 + 1800 * H * 4 + Ee * H * 4)
+    add("bag forward (L2 row traffic Z*H*4)", us, k, Z * H * 4)
+    dt = torch.empty(1800, H, device=dev)
+    scr = torch.empty(int(nv.lib().esc_bag_bwd_scratch(Z, H)), device=dev)
+    us, k = timed("bag_bwd", lambda: nv.call("esc_bag_bwd_table_rows", nv.ptr(zb), H, H, nv.ptr(plan.col_ptr), nv.ptr(plan.col_row), nv.ptr(plan.col_val), nv.ptr(plan.col_col), Z, 1800, Ee, 0, nv.ptr(dt), nv.ptr(scr), s))
+    add("bag table gradient, XCD-aware (HBM bytes)", us, k, Ee * H * 4 + Z * 8 + 1800 * H * 4)
+    add("bag table gradient (L2 row traffic)", us, k, Z * H * 4)
+    us, k = timed("bag_bwd", lambda: nv.call("esc_bag_bwd_table", nv.ptr(zb), H, H, nv.ptr(plan.col_ptr), nv.ptr(plan.col_row), nv.ptr(plan.col_val), nv.ptr(plan.col_col), Z, 1800, nv.ptr(dt), nv.ptr(scr), s))
+    add("bag table gradient, chunks in linear order", us, k, Z * H * 4)
+    ids = torch.arange(128)
+    us, k = timed("collate", lambda: store.collate(ids), n=30)
+    add("device collate (2 kernels)", us, k, 27e6)
+    # BatchNorm passes, edge-sized
+    M = Ee
+    xx = torch.randn(M, H, device=dev); yy = torch.randn(M, H, device=dev); dy = torch.randn(M, H, device=dev); dxx = torch.empty(M, H, device=dev)
+    mean = torch.zeros(H, device=dev); inv = torch.ones(H, device=dev); ga = torch.ones(H, device=dev); be = torch.zeros(H, device=dev)
+    dg = torch.empty(H, device=dev); db = torch.empty(H, device=dev); sc = torch.ones(H, device=dev); sh = torch.zeros(H, device=dev)
+    scratch = torch.empty(nv.lib().esc_bn_scratch(H), device=dev)
+    us, k = timed("norm", lambda: nv.call("esc_bn_bwd", nv.ptr(xx), H, None, 0, nv.ptr(dy), H, M, H, nv.ptr(mean), nv.ptr(inv), nv.ptr(ga), nv.ptr(be), 1, nv.ptr(dxx), H, nv.ptr(dg), nv.ptr(db), nv.ptr(scratch), s))
+    add("BatchNorm backward, edge rows (3 kernels)", us, k, 5 * M * H * 4)
+    us, k = timed("norm", lambda: nv.call("esc_affine_act", nv.ptr(xx), H, M, H, nv.ptr(sc), nv.ptr(sh), 1, nv.ptr(yy), H, s))
+    add("affine + ReLU, edge rows", us, k, 2 * M * H * 4)
+    # GEMMs
+    w = torch.randn(H, H, device=dev); bias = torch.randn(H, device=dev)
+    for name, rows_ in (("edge rows 15200x256x256", Ee), ("node rows 2400x256x256", N)):
+        a = torch.randn(rows_, H, device=dev); c = torch.empty(rows_, H, device=dev)
+        us, k = timed("linear", lambda: nv.call("esc_linear_fwd", nv.ptr(a), H, nv.ptr(w), H, nv.ptr(bias), None, None, rows_, H, H, nv.ptr(c), H, None, s))
+        add("Linear forward, " + name, us, k, flops=2.0 * rows_ * H * H)
+        dw = torch.empty(H, H, device=dev); dbb = torch.empty(H, device=dev); da = torch.empty(rows_, H, device=dev)
+        slabs = torch.empty(int(nv.lib().esc_linear_bwd_weight_scratch(rows_, H, H)), device=dev)
+        us, k = timed("linear", lambda: nv.call("esc_linear_bwd_both", nv.ptr(c), H, nv.ptr(a), H, None, None, nv.ptr(w), H, rows_, H, H, nv.ptr(da), H, 0, nv.ptr(dw), H, nv.ptr(dbb), nv.ptr(slabs), s))
+        add("Linear backward dX+dW (+reduce), " + name, us, k, flops=4.0 * rows_ * H * H)
+    print("MI355X, BASELINE config 1 shapes: N=%d E=%d Z=%d H=%d; peaks: HBM %.0f GB/s, fp32 MFMA %.1f TFLOP/s" % (N, Ee, Z, H, HBM, MFMA))
+    head = ("kernel (back to back)", "us/call", "launches", "algorithmic", "achieved", "of peak")
+    wid = [max(len(r[i]) for r in rows + [head]) for i in range(6)]
+    for r in [head] + rows:
+        print("  ".join(r[i].ljust(wid[i]) for i in range(6)))
+
+
+if __name__ == "__main__":
+    main()
