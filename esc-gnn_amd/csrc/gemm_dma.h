@@ -1,0 +1,538 @@
+// gemm_dma.h — the fp32 MFMA GEMMs of the hot shapes, staged by LDS-DMA (buffer_load ... lds).
+//
+// One tile body, three operand combinations (KC = k-contiguous: the reduction index is the fastest-moving index in
+// memory; RM = reduction-major: the reduction index is the row index in memory):
+//   NT  A KC, B KC :  Y[M,N]  = act(X)[M,K] * W[N,K]^T + b          torch.nn.Linear forward
+//   NN  A KC, B RM :  dX[M,K] = dY[M,N] * W[N,K]                     its input gradient
+//   TN  A RM, B RM :  dW[N,K] = dY[M,N]^T * act(X)[M,K] (+ db)       its weight gradient, split over M into slabs
+//
+// Call sites replaced: every torch.nn.Linear / GINEConv.lin of /root/reference/run_graphcount.py:54-121,183-189
+// (zinc_models.py:513-576, ogb_mol_gnn.py:330-345) whose reduction length is a multiple of 32 — the H-wide layers,
+// >99 % of a training step's flops.  Ragged shapes (in_dim 10, ...) stay on linear_mfma.hip.
+//
+// Why a second GEMM family: these shapes are SHORT-K (K = 256: 8 K-steps per tile), so prologue, per-step issue
+// overhead and epilogue are first-order costs (measured on MI355X for a 128x128x256 tile of the r01 kernel design:
+// K loop 37 k cycles for 32.8 k cycles of MFMA, epilogue 17.7 k cycles).  Here
+//   * tiles land in LDS by DMA (one 1-KiB piece per wave-instruction, no VGPR staging, no ds_write); row bounds come
+//     from the buffer descriptor (out-of-range rows read as zero): no clamps, no masks, no per-step VALU;
+//   * optional LOADER waves issue the DMA, so a compute wave's stream is barrier / ds_read / MFMA only (a piece costs
+//     its issuing wave 60-180 cycles; 8 per K-step is 10-35 % of the step's 4096 MFMA cycles): K loop 34.3 k cycles;
+//   * KC images are unpadded and XOR-swizzled on the SOURCE address (the DMA writes lane-linear): conflict-free
+//     ds_read_b128 fragments; RM images are read with ds_read_b32 (consecutive lanes, consecutive banks);
+//   * STAGES-deep ring with counted vmcnt and ONE raw s_barrier per K-step;
+//   * the output tile is staged through LDS (dead by then) and leaves as whole rows, 16 bytes per lane (16 dword
+//     stores per 32x32 block straight from the accumulators cost 17.7 k cycles, staged: 4.5 k, HBM-bound);
+//   * v_mfma_f32_32x32x2_f32: exact fp32 fma chain (no TF32 on gfx950); lane half h owns k = 8c+4h+t of every
+//     8-chunk, the same permutation for both operands.
+#pragma once
+#include "common.h"
+
+namespace esc {
+namespace dma {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+using lds_void = __attribute__((address_space(3))) void;
+
+// raw buffer descriptor (stride 0): accesses at byte offsets >= `bytes` read as zero / are dropped
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  i32x4 r;
+  r[0] = (int)(uint32_t)a; r[1] = (int)(uint32_t)((a >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(uintptr_t)(lds_void*)const_cast<float*>(p);
+}
+// one 1-KiB piece: lane i moves 16 bytes from (base + voff + soff) to LDS byte (dst + 16 i); dst wave-uniform.
+// (voff is bounds-checked against the descriptor, soff is not.)
+// Issued from inline asm on purpose: hipcc would otherwise drain vmcnt(0) before every LDS read that follows a DMA it can
+// see, i.e. once per K-step, and the ring below would never overlap a transfer with the MFMAs.  The statement is
+// therefore absent from the compiler's vmcnt bookkeeping: completion is counted by hand (wait_vmcnt + s_barrier).
+// M0 is compiler-reserved: saved and restored inside the statement; s_nop 4 covers an SGPR operand freshly written by SALU.
+__device__ __forceinline__ void dma16(i32x4 r, unsigned dst, int voff, int soff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(r), "s"(dst), "s"(soff)
+      : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// swizzle of the 16-byte chunk index inside a k-contiguous LDS row: the 16 lanes of a ds_read_b128 group read 16
+// different rows at one logical chunk; with 128-byte rows (BK 32) two rows share a 256-byte bank line, so the key is
+// (row >> 1) & 7; with 256-byte rows (BK 64) it is row & 15.
+template <int BK> __device__ __forceinline__ int swz(int row) {
+  static_assert(BK == 32 || BK == 64, "BK is 32 or 64");
+  return BK == 32 ? ((row >> 1) & 7) : (row & 15);
+}
+
+struct GArgs {
+  const float* A; int lda;           // KC: [M, R]   RM: [R, M]
+  const float* B; int ldb;           // KC: [N, R]   RM: [R, N]
+  float* C; int ldc;                 // [M, N]; with splits > 1: slabs [split][M][N] (ldc = N)
+  const float* bias;                 // [N] or null
+  const float* pro_scale;            // PRO 1: [R] on A (KC)   PRO 2: [N] on B (RM):  x := relu(x * scale + shift)
+  const float* pro_shift;
+  float2* col_stats;                 // [ceil(M/32)][N] (mean, M2) of the outputs, or null (STATS)
+  float* db_part;                    // DB: per-split sums over the reduction of A's columns, [split][M]
+  int M, N, R;                       // output rows, output cols, reduction length
+  int red_per_split;                 // multiple of BK; splits = ceil(R / red_per_split)
+  int accumulate;                    // C += ...
+  int c_vec;                         // set by the launcher: 16-byte row stores are legal
+  int ntile_m, ntile_n;              // set by the launcher
+  unsigned long long* stamps;        // diagnostics (tools/gemm_lab): per workgroup clock readings, or null
+};
+
+__device__ __forceinline__ void stamp(unsigned long long* base, int slot) {
+  if (base != nullptr) {                                  // wave-uniform
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_readcyclecounter();
+    const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { base[blockIdx.x * 12 + slot] = t; base[blockIdx.x * 12 + 6 + slot] = r; }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// tile sequence number of a workgroup: workgroups b and b+8 share an XCD (dealt round-robin), so the sequence is cut
+// into 8 contiguous runs — consecutive tiles (same row panel of A) meet in one L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
+struct Cfg {
+  static constexpr int NW = WM * WN, NWT = NW + LW, NTHR = NWT * 64, DW = LW > 0 ? LW : NW;
+  static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE_FLOATS = A_FLOATS + B_FLOATS;
+  static constexpr int PA = A_FLOATS / 256, PB = B_FLOATS / 256;        // 1-KiB pieces per tile
+  static constexpr int PPWA = PA / DW, PPWB = PB / DW, PPW = PPWA + PPWB;
+  static constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
+  static constexpr int OUT_LD = BN + 4, OUT_FLOATS = BM * OUT_LD;       // epilogue staging image [BM][BN+4]
+  static constexpr int RING_FLOATS = STAGES * STAGE_FLOATS > OUT_FLOATS ? STAGES * STAGE_FLOATS : OUT_FLOATS;
+  static constexpr int PRO_MAXK = 1280;
+  static constexpr int PRO_FLOATS = PRO == 1 ? 2 * PRO_MAXK : 0;        // scale | shift of the whole reduction range
+  static constexpr size_t LDS_BYTES = (size_t)(RING_FLOATS + PRO_FLOATS) * 4;
+  static constexpr int C4 = BN / 4;                                     // float4 per output row of the tile
+  static_assert(PA % DW == 0 && PB % DW == 0, "pieces must split evenly over the DMA waves");
+  static_assert(MT >= 1 && NT >= 1 && STAGES >= 2 && STAGES <= 4, "bad tile");
+  static_assert(NTHR % C4 == 0, "a thread keeps one column quad through the epilogue");
+  static_assert(PRO == 0 || (PRO == 1 && !A_RM) || (PRO == 2 && B_RM), "prologue: per-k on a KC A, or per-column on an RM B");
+  static_assert(!DB || A_RM, "bias gradient = column sums of a reduction-major A");
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+};
+
+// ---- per-lane DMA source offsets of one operand tile -------------------------------------------------------------
+// KC tile [T][BK]: piece p holds rows p RPP .. ; lane: row = p RPP + l / CPR, physical chunk l % CPR holding logical
+//   chunk (l % CPR) ^ swz(row).  Offset = (o0 + row) ld 4 + chunk 16; the K-step goes through soff = kt BK 4.
+// RM tile [BK][T]: piece p holds reduction rows p RPP .. ; offset = (red0 + row) ld 4 + (o0 + col) 4; the K-step is ADDED
+//   to the offsets (it must be bounds-checked: rows past the split's end read as zero).
+template <int T, int BK, int DW, int NP, bool RM>
+__device__ __forceinline__ void dma_offsets(int (&vo)[NP], int dw, int l, int o0, int red0, int ld) {
+  if constexpr (!RM) {
+    constexpr int RB = BK * 4, CPR = RB / 16, RPP = 1024 / RB;
+    const int prow = l / CPR, pc = l % CPR;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int row = (dw + DW * j) * RPP + prow;
+      vo[j] = ((o0 + row) * ld) * 4 + ((pc ^ swz<BK>(row)) << 4);
+    }
+  } else {
+    constexpr int RB = T * 4, CPR = RB / 16, RPP = 1024 / RB;
+    static_assert(RB <= 1024, "RM tile rows longer than one DMA piece are not supported");
+    const int prow = l / CPR, pc = l % CPR;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int row = (dw + DW * j) * RPP + prow;
+      vo[j] = ((red0 + row) * ld + o0) * 4 + (pc << 4);
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
+__device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ lds, int wg) {
+  using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
+  constexpr int NW = C_::NW, DW = C_::DW;
+  constexpr int PPWA = C_::PPWA, PPWB = C_::PPWB, PPW = C_::PPW;
+  constexpr int TM = C_::TM, TN = C_::TN, MT = C_::MT, NT = C_::NT;
+  constexpr int RB = BK * 4;
+
+  const int per = g.ntile_m * g.ntile_n;
+  const int split = wg / per;
+  const int tile = xcd_tile_id(wg % per, per);
+  const int m0 = (tile / g.ntile_n) * BM, n0 = (tile % g.ntile_n) * BN;
+  const int red0 = split * g.red_per_split;
+  const int red1 = min(g.R, red0 + g.red_per_split);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l = lane_id(), h = l >> 5, lr = l & 31;
+  const bool loader = LW > 0 && wave >= NW;                 // wave-uniform
+  const bool issuing = LW == 0 || loader;
+  const int dw = LW > 0 ? wave - NW : wave;                 // index among the DMA-issuing waves
+  const int wm = (wave % NW) / WN, wn = wave % WN;
+
+  const i32x4 ra = A_RM ? make_rsrc(g.A, (unsigned)(((size_t)(red1 - 1) * g.lda + g.M) * 4))
+                        : make_rsrc(g.A, (unsigned)(((size_t)(g.M - 1) * g.lda + g.R) * 4));
+  const i32x4 rb = B_RM ? make_rsrc(g.B, (unsigned)(((size_t)(red1 - 1) * g.ldb + g.N) * 4))
+                        : make_rsrc(g.B, (unsigned)(((size_t)(g.N - 1) * g.ldb + g.R) * 4));
+  int voa[PPWA], vob[PPWB];
+  dma_offsets<BM, BK, DW, PPWA, A_RM>(voa, dw, l, m0, red0, g.lda);
+  dma_offsets<BN, BK, DW, PPWB, B_RM>(vob, dw, l, n0, red0, g.ldb);
+  const int stepa = A_RM ? BK * g.lda * 4 : 0, stepb = B_RM ? BK * g.ldb * 4 : 0;   // RM: K-step inside the checked offset
+
+  const unsigned lds_base = lds_addr(lds);
+  int issued = 0;                                           // K-steps issued so far by this wave
+  auto stage = [&](int buf) {
+    const unsigned a_dst = lds_base + (unsigned)(buf * C_::STAGE_FLOATS + dw * 256) * 4u;
+    const unsigned b_dst = a_dst + C_::A_FLOATS * 4u;
+    const int soff = (red0 + issued * BK) * 4;              // KC operands: K offset, never out of range
+#pragma unroll
+    for (int j = 0; j < PPWA; ++j) {
+      dma16(ra, a_dst + (unsigned)(DW * j) * 1024u, voa[j], A_RM ? 0 : soff);
+      if constexpr (A_RM) voa[j] += stepa;
+    }
+#pragma unroll
+    for (int j = 0; j < PPWB; ++j) {
+      dma16(rb, b_dst + (unsigned)(DW * j) * 1024u, vob[j], B_RM ? 0 : soff);
+      if constexpr (B_RM) vob[j] += stepb;
+    }
+    ++issued;
+  };
+  // tile kt of this wave's pieces has landed once at most `ahead` younger groups are still in flight
+  auto wait_tile = [&](int ahead) {
+    if (ahead <= 0) wait_vmcnt<0>();
+    else if (ahead == 1) wait_vmcnt<PPW>();
+    else wait_vmcnt<(STAGES >= 4 ? 2 : 1) * PPW>();
+  };
+
+  stamp(g.stamps, 0);
+  const int nk = (red1 - red0 + BK - 1) / BK;
+  if (issuing) {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) stage(s);
+  }
+
+  float* pro = lds + C_::RING_FLOATS;     // PRO 1: [scale R | shift R]
+  if constexpr (PRO == 1) {
+    for (int k = threadIdx.x; k < g.R; k += C_::NTHR) { pro[k] = g.pro_scale[k]; pro[C_::PRO_MAXK + k] = g.pro_shift[k]; }
+  }
+  float cs[NT], ch_[NT];                  // PRO 2: this lane's column coefficients (column = lane & 31 of each block)
+  if constexpr (PRO == 2) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * TN + j * 32 + lr;
+      cs[j] = col < g.N ? g.pro_scale[col] : 0.f;
+      ch_[j] = col < g.N ? g.pro_shift[col] : 0.f;
+    }
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float dbsum = 0.f;
+
+  // fragment addressing.  KC: row (lane & 31) of a 32-row block, logical chunk 2 c8 + h -> physical (2 c8) ^ y.
+  // RM: reduction row 8 c8 + 4 h + t, column (lane & 31) of a 32-column block.
+  const int y16 = (h ^ swz<BK>(lr)) << 4;
+  const int a_base = A_RM ? (h * 4 * BM + wm * TM + lr) * 4 : (wm * TM + lr) * RB;
+  const int b_base = B_RM ? (h * 4 * BN + wn * TN + lr) * 4 : (wn * TN + lr) * RB;
+
+  auto compute = [&](int buf, int kt) {
+    const char* a_l = reinterpret_cast<const char*>(lds + buf * C_::STAGE_FLOATS);
+    const char* b_l = a_l + C_::A_FLOATS * 4;
+    if constexpr (DB) {     // column sums of the reduction-major A tile (bias gradient): first column tile only
+      if (n0 == 0 && (int)threadIdx.x < BM) {
+        const float* col = reinterpret_cast<const float*>(a_l) + threadIdx.x;
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) dbsum += col[kk * BM];
+      }
+    }
+    float4 af[2][MT], bf[2][NT], s4[2], h4[2];
+    auto frags = [&](int c8, int q) {
+      const int ch = (c8 << 5) ^ y16;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if constexpr (!A_RM) {
+          af[q][i] = *reinterpret_cast<const float4*>(a_l + a_base + i * 32 * RB + ch);
+        } else {
+          const float* p = reinterpret_cast<const float*>(a_l + a_base + (c8 * 8 * BM + i * 32) * 4);
+          af[q][i] = make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (!B_RM) {
+          bf[q][j] = *reinterpret_cast<const float4*>(b_l + b_base + j * 32 * RB + ch);
+        } else {
+          const float* p = reinterpret_cast<const float*>(b_l + b_base + (c8 * 8 * BN + j * 32) * 4);
+          bf[q][j] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+        }
+      }
+      if constexpr (PRO == 1) {
+        const int k = red0 + kt * BK + c8 * 8 + h * 4;
+        s4[q] = *reinterpret_cast<const float4*>(pro + k);
+        h4[q] = *reinterpret_cast<const float4*>(pro + C_::PRO_MAXK + k);
+      }
+    };
+    constexpr int NREADS = (A_RM ? 4 : 1) * MT + (B_RM ? 4 : 1) * NT + (PRO == 1 ? 2 : 0);
+    constexpr int NVALU = PRO == 1 ? 8 * MT : (PRO == 2 ? 8 * NT : 0);
+    constexpr int NMFMA = 4 * MT * NT;
+    auto transform = [&](int q) {         // consumer-side BatchNorm + ReLU on the staged operand
+      if constexpr (PRO == 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float4& v = af[q][i];
+          v.x = fmaxf(fmaf(v.x, s4[q].x, h4[q].x), 0.f); v.y = fmaxf(fmaf(v.y, s4[q].y, h4[q].y), 0.f);
+          v.z = fmaxf(fmaf(v.z, s4[q].z, h4[q].z), 0.f); v.w = fmaxf(fmaf(v.w, s4[q].w, h4[q].w), 0.f);
+        }
+      }
+      if constexpr (PRO == 2) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float4& v = bf[q][j];
+          v.x = fmaxf(fmaf(v.x, cs[j], ch_[j]), 0.f); v.y = fmaxf(fmaf(v.y, cs[j], ch_[j]), 0.f);
+          v.z = fmaxf(fmaf(v.z, cs[j], ch_[j]), 0.f); v.w = fmaxf(fmaf(v.w, cs[j], ch_[j]), 0.f);
+        }
+      }
+    };
+    frags(0, 0);
+    transform(0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+    if constexpr (NVALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+#pragma unroll
+    for (int c8 = 0; c8 < BK / 8; ++c8) {
+      const int cur = c8 & 1;
+      const bool more = c8 + 1 < BK / 8;
+      if (more) frags(c8 + 1, cur ^ 1);     // the next chunk's fragments fly under this chunk's MFMAs ...
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].x, bf[cur][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].y, bf[cur][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].z, bf[cur][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].w, bf[cur][j].w, acc[i][j], 0, 0, 0);
+        }
+      if (more) transform(cur ^ 1);         // ... and are transformed in the shadow of its second half
+      // pin the order (hipcc otherwise sinks the reads below the MFMAs to save registers): reads, MFMAs, transform, MFMAs
+      if (more) __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+      if constexpr (NVALU > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / 2, 0);
+        if (more) __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NMFMA / 2, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+      }
+    }
+  };
+
+  // ring: at the top of step kt the DMA groups of tiles kt .. kt+STAGES-2 are in flight; the issuing waves wait for
+  // the oldest, everyone meets (all pieces of tile kt have landed AND everyone is done reading tile kt-1), the buffer
+  // tile kt-1 lived in is refilled with tile kt+STAGES-1, tile kt is computed.
+  if (loader) {
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_tile(min(STAGES - 2, nk - 1 - kt));
+      __builtin_amdgcn_s_barrier();
+      if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES);
+    }
+  } else {
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+      for (int s = 0; s < STAGES; ++s) {
+        const int kt = kt0 + s;
+        if (kt < nk) {
+          if constexpr (LW == 0) wait_tile(min(STAGES - 2, nk - 1 - kt));
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          if (kt == 0) stamp(g.stamps, 1);
+          if constexpr (LW == 0) {
+            if (kt + STAGES - 1 < nk) stage((s + STAGES - 1) % STAGES);
+          }
+          compute(s, kt);
+        }
+      }
+    }
+  }
+  stamp(g.stamps, 2);
+
+  // ---- BatchNorm partials of the outputs (bias included): one (mean, M2) per column and 32-row block
+  if constexpr (STATS) {
+    if (g.col_stats != nullptr && !loader) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + wn * TN + j * 32 + lr;
+          const int row0 = m0 + wm * TM + i * 32;
+          const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+          const int nvalid = min(32, g.M - row0);
+          float mean, m2 = 0.f;
+          if (nvalid >= 32) {             // interior block (wave-uniform): no row masks
+            float s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1 += acc[i][j][r] + bv;
+            s1 += __shfl_xor(s1, 32, 64);
+            mean = s1 * (1.f / 32.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc[i][j][r] + bv - mean; m2 = fmaf(d, d, m2); }
+          } else {
+            float s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              if (row < g.M) s1 += acc[i][j][r] + bv;
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            mean = nvalid > 0 ? s1 / (float)nvalid : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              if (row < g.M) { const float d = acc[i][j][r] + bv - mean; m2 = fmaf(d, d, m2); }
+            }
+          }
+          m2 += __shfl_xor(m2, 32, 64);
+          if (l < 32 && col < g.N && nvalid > 0) g.col_stats[(size_t)(row0 / 32) * g.N + col] = make_float2(mean, m2);
+        }
+    }
+  }
+  if constexpr (DB) {
+    if (n0 == 0 && (int)threadIdx.x < BM && m0 + (int)threadIdx.x < g.M)
+      g.db_part[(size_t)split * g.M + m0 + threadIdx.x] = dbsum;
+  }
+  // ---- epilogue: the tile is staged through LDS (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h) and
+  // leaves as whole rows, 16 bytes per lane
+  __syncthreads();                                           // everyone is done reading the last K tile
+  if (!loader) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          lds[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * C_::OUT_LD + wn * TN + j * 32 + lr] = acc[i][j][r];
+  }
+  __syncthreads();
+  {
+    constexpr int C4 = C_::C4, RPI = C_::NTHR / C4, ITERS = (BM + RPI - 1) / RPI;      // rows per pass, passes
+    const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
+    const int col = n0 + c4 * 4;
+    float* Cb = g.C + (size_t)split * g.M * g.ldc;           // split > 0 only for slab outputs
+    if (g.c_vec) {
+      if (col < g.N) {                                       // N % 4 == 0: whole quads only
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + col);
+        float* cp = Cb + (size_t)(m0 + rr) * g.ldc + col;
+        const size_t step = (size_t)RPI * g.ldc;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int row = m0 + rr + it * RPI;
+          if (row < g.M && (BM % RPI == 0 || rr + it * RPI < BM)) {
+            float4 v = *reinterpret_cast<const float4*>(lds + (rr + it * RPI) * C_::OUT_LD + c4 * 4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            float4* dst = reinterpret_cast<float4*>(cp + it * step);
+            if (g.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *dst = v;
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it < ITERS; ++it) {
+        const int row = m0 + rr + it * RPI;
+        if (row >= g.M || rr + it * RPI >= BM) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (col + q < g.N) {
+            float v = lds[(rr + it * RPI) * C_::OUT_LD + c4 * 4 + q] + (g.bias ? g.bias[col + q] : 0.f);
+            float* dst = Cb + (size_t)row * g.ldc + col + q;
+            if (g.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    }
+  }
+  if (g.stamps != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  stamp(g.stamps, 3);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
+__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_kernel(GArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  gemm_body<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>(g, lds, (int)blockIdx.x);
+}
+
+// Backward of one Linear in ONE launch: the first workgroups compute the dX tiles (NN), the rest the split-M dW slabs
+// (TN).  Both stream the same dY; one launch instead of two removes a boundary and lets the two under-filled grids
+// of the node-sized layers share the chip.
+struct DualArgs { GArgs dx, dw; int n_dx; };
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
+__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_dual_kernel(DualArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = (int)blockIdx.x;
+  if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>(a.dx, lds, b);
+  else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>(a.dw, lds, b - a.n_dx);
+}
+
+inline int splits_of(const GArgs& g) { return g.red_per_split >= g.R ? 1 : (int)cdiv(g.R, g.red_per_split); }
+
+template <typename K>
+inline hipError_t raise_lds(K kern, size_t lds, size_t& raised_to) {
+  if (lds > raised_to) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    raised_to = lds;
+  }
+  return hipSuccess;
+}
+
+template <int BM, int BN>
+inline void finish_args(GArgs& g) {
+  g.c_vec = (g.N % 4 == 0 && g.ldc % 4 == 0 && aligned16(g.C) && (g.bias == nullptr || aligned16(g.bias))) ? 1 : 0;
+  g.ntile_m = (int)cdiv(g.M, BM);
+  g.ntile_n = (int)cdiv(g.N, BN);
+  if (g.red_per_split <= 0 || g.red_per_split > g.R) g.red_per_split = g.R;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
+inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
+  using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
+  auto kern = gemm_kernel<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
+  const size_t lds = C_::LDS_BYTES > lds_floor ? C_::LDS_BYTES : lds_floor;
+  static size_t raised_to = 64 * 1024;      // per instantiation
+  hipError_t e = raise_lds(kern, lds, raised_to);
+  if (e != hipSuccess) return e;
+  finish_args<BM, BN>(g);
+  const unsigned nwg = (unsigned)(g.ntile_m * g.ntile_n * splits_of(g));
+  esc::launch(kind, kern, dim3(nwg), dim3(C_::NTHR), lds, s, g);
+  return hipSuccess;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
+inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
+  using CX = Cfg<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>;
+  using CW = Cfg<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>;
+  auto kern = gemm_dual_kernel<BM, BN, BK, WM, WN, STAGES, LW, PRO>;
+  size_t lds = CX::LDS_BYTES > CW::LDS_BYTES ? CX::LDS_BYTES : CW::LDS_BYTES;
+  if (lds_floor > lds) lds = lds_floor;
+  static size_t raised_to = 64 * 1024;
+  hipError_t e = raise_lds(kern, lds, raised_to);
+  if (e != hipSuccess) return e;
+  finish_args<BM, BN>(a.dx);
+  finish_args<BM, BN>(a.dw);
+  a.n_dx = a.dx.ntile_m * a.dx.ntile_n;
+  const unsigned nwg = (unsigned)(a.n_dx + a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw));
+  esc::launch(kind, kern, dim3(nwg), dim3(CX::NTHR), lds, s, a);
+  return hipSuccess;
+}
+
+}  // namespace dma
+}  // namespace esc

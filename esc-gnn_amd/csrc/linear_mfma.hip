@@ -21,6 +21,7 @@
 // dW).  LDS image [k][cols+4]; a lane reads single floats (ds_read_b32, consecutive lanes ->
 // consecutive banks).
 #include "common.h"
+#include "gemm_dma.h"
 #include <type_traits>
 
 namespace esc {
@@ -880,6 +881,67 @@ enum { KNOB_FWD_BIG = 0, KNOB_FWD_SMALL = 1, KNOB_DX_BIG = 2, KNOB_DX_SMALL = 3,
        KNOB_DW_BLOCKS = 5, KNOB_DW_MIN_ROWS = 6, KNOB_DUAL_SMALL = 7, KNOB_COUNT = 8 };
 static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128, 2};
 
+
+// ---- dispatch to the LDS-DMA family (gemm_dma.h): the H-wide layers ---------------------------------------------
+// knob 11 (default 1): 0 keeps every GEMM on the r01 register-staged tiles above (A/B runs in one process)
+static int g_use_dma = 1;
+static inline bool dma_ok(const void* p, int64_t rows, int64_t ld) {
+  return aligned16(p) && ld % 4 == 0 && rows * ld * 4 < (1LL << 31);
+}
+static inline hipError_t dma_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) set_error("%s: %s", what, hipGetErrorString(e));
+  return e;
+}
+// split-M plan of the weight gradient for a BMxBN output tile: ~one workgroup per CU, splits >= 128 rows deep
+static void dma_wgrad_plan(int64_t M, int64_t N, int64_t K, int bm, int bn, int* splits, int* per) {
+  const int64_t tiles = cdiv(N, bm) * cdiv(K, bn);
+  int64_t sp = cdiv(256, tiles);
+  const int64_t max_sp = cdiv(M, 128);
+  if (sp > max_sp) sp = max_sp;
+  if (sp < 1) sp = 1;
+  int64_t pr = cdiv(cdiv(M, sp), 32) * 32;
+  if (pr < 128) pr = 128;
+  *per = (int)pr;
+  *splits = (int)cdiv(M, pr);
+}
+static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias, const float* in_scale,
+                    const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y, float* col_stats,
+                    hipStream_t s, int* rc) {
+  if (!g_use_dma || K % 32 != 0 || N <= 32 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && K > 1280)) return false;
+  dma::GArgs g{};
+  g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
+  g.pro_scale = in_scale; g.pro_shift = in_shift; g.col_stats = reinterpret_cast<float2*>(col_stats);
+  g.M = (int)M; g.N = (int)N; g.R = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
+  hipError_t e;
+  if (M >= 8192 && N >= 128) {     // edge-sized: 128x128 tile, 4 compute + 4 loader waves, one workgroup per CU
+    e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s)
+                 : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
+  } else {                         // node-sized: 64x64 tile, 4 compute + 2 loader waves
+    e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 1, true, false>(g, 0, s)
+                 : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 0, true, false>(g, 0, s);
+  }
+  *rc = dma_check(e, "esc_linear_fwd") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
+  return true;
+}
+static bool dma_bwd_ok(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* W, int64_t ld_w,
+                       int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx, const float* slabs, bool need_dx,
+                       bool need_dw) {
+  if (!g_use_dma || N <= 32 || K <= 32 || N % 4 != 0 || K % 4 != 0 || !dma_ok(dY, M, ld_dy)) return false;
+  if (need_dx && (N % 32 != 0 || !dma_ok(W, N, ld_w) || !dma_ok(dX, M, ld_dx))) return false;
+  if (need_dw && (!dma_ok(X, M, ld_x) || !aligned16(slabs))) return false;
+  return true;
+}
+static void dma_fill_dx(dma::GArgs& g, const float* dY, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M, int64_t N,
+                        int64_t K, float* dX, int64_t ld_dx, int accumulate) {
+  g.A = dY; g.lda = (int)ld_dy; g.B = W; g.ldb = (int)ld_w; g.C = dX; g.ldc = (int)ld_dx;
+  g.M = (int)M; g.N = (int)K; g.R = (int)N; g.red_per_split = (int)N; g.accumulate = accumulate;
+}
+static void dma_fill_dw(dma::GArgs& g, const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* in_scale,
+                        const float* in_shift, int64_t M, int64_t N, int64_t K, float* slabs, int splits, int per) {
+  g.A = dY; g.lda = (int)ld_dy; g.B = X; g.ldb = (int)ld_x; g.C = slabs; g.ldc = (int)K;
+  g.pro_scale = in_scale; g.pro_shift = in_shift; g.db_part = slabs + (size_t)splits * N * K;
+  g.M = (int)N; g.N = (int)K; g.R = (int)M; g.red_per_split = per; g.accumulate = 0;
+}
 }  // namespace esc
 
 using namespace esc;
@@ -911,6 +973,7 @@ int esc_tune_set(int knob, int value) {
   if (knob == 8) { set_last_block_finalize(value); return ESC_OK; }
   if (knob == 9) { set_norm_rowblock_cap(value); return ESC_OK; }
   if (knob == 10) { set_edge_lds_floor(value); return ESC_OK; }
+  if (knob == 11) { g_use_dma = value != 0; return ESC_OK; }
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
   g_knob[knob] = value;
   return ESC_OK;
@@ -940,6 +1003,14 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
 #undef ESC_NARROW_FWD
     ESC_CHECK_LAUNCH("esc_linear_fwd.narrow");
     return ESC_OK;
+  }
+  if (bn == nullptr || M > FUSE_FINALIZE_MAX_ROWS || !last_block_finalize()) {
+    int rc = ESC_OK;
+    if (dma_fwd(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, s, &rc)) {
+      if (rc != ESC_OK || bn == nullptr) return rc;
+      return esc_bn_stats_from_partials(col_stats, M, N, bn->eps, bn->momentum, bn->mean, bn->invstd, bn->running_mean,
+                                        bn->running_var, bn->gamma, bn->beta, bn->scale, bn->shift, stream);
+    }
   }
   GemmArgs g{};
   g.A = X; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.C = Y; g.ldc = ld_y; g.bias = bias;
@@ -1003,6 +1074,13 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
     else        esc::launch(ESC_K_LINEAR, linear_narrow_dx<16>, dim3(blocks), dim3(256), 0, s, dY, ld_dy, W, ld_w, (int)M, (int)N, (int)K, dX, ld_dx, accumulate);
     ESC_CHECK_LAUNCH("esc_linear_bwd_input.narrow");
     return ESC_OK;
+  }
+  if (dma_bwd_ok(dY, ld_dy, nullptr, 0, W, ld_w, M, N, K, dX, ld_dx, nullptr, true, false)) {
+    dma::GArgs d{};
+    dma_fill_dx(d, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
+    const hipError_t e = M >= 8192 ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s)
+                                   : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, true, 0, false, false>(d, 0, s);
+    return dma_check(e, "esc_linear_bwd_input") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
   }
   GemmArgs g{};
   g.A = dY; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.C = dX; g.ldc = ld_dx; g.bias = nullptr;
@@ -1069,6 +1147,24 @@ static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t l
   ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_weight: dimension too large");
   hipStream_t s = (hipStream_t)stream;
   int splits, per;
+  if (dma_bwd_ok(dY, ld_dy, X, ld_x, nullptr, 0, M, N, K, nullptr, 0, slabs, false, true)) {
+    const bool big = M >= 8192;
+    dma_wgrad_plan(M, N, K, big ? 128 : 64, big ? 128 : 64, &splits, &per);
+    dma::GArgs d{};
+    dma_fill_dw(d, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
+    hipError_t e;
+    if (big) e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 2, false, true>(d, 0, s)
+                          : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 0, false, true>(d, 0, s);
+    else     e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, true, true, 2, false, true>(d, 0, s)
+                          : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, true, true, 0, false, true>(d, 0, s);
+    if (dma_check(e, "esc_linear_bwd_weight") != hipSuccess) return ESC_ELAUNCH;
+    const int64_t n = N * K;
+    if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, d.db_part, N, db); return ESC_OK; }
+    esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+                splits, (int)K, dW, ld_dw, d.db_part, (int)N, db);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_weight.reduce");
+    return ESC_OK;
+  }
   wgrad_plan(M, N, K, &splits, &per);
   GemmArgs g{};
   g.A = dY; g.lda = ld_dy; g.B = X; g.ldb = ld_x; g.C = slabs; g.ldc = K; g.bias = nullptr;
@@ -1182,6 +1278,27 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
     esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
                 splits, (int)K, dW, ld_dw, db_part, (int)N, db);
     ESC_CHECK_LAUNCH("esc_linear_bwd_both.narrow_reduce");
+    return ESC_OK;
+  }
+  if (dX != nullptr && M > 0 && M < (1LL << 31) && ld_dw >= K && (in_scale == nullptr) == (in_shift == nullptr) &&
+      dma_bwd_ok(dY, ld_dy, X, ld_x, W, ld_w, M, N, K, dX, ld_dx, slabs, true, true)) {
+    // dX tiles + split-M dW slabs of the LDS-DMA family in ONE launch
+    hipStream_t s = (hipStream_t)stream;
+    const bool big = M >= 8192;
+    int splits, per;
+    dma_wgrad_plan(M, N, K, big ? 128 : 64, big ? 128 : 64, &splits, &per);
+    dma::DualArgs a{};
+    dma_fill_dx(a.dx, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
+    dma_fill_dw(a.dw, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
+    hipError_t e;
+    if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false>(a, 0, s);
+    else     e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false>(a, 0, s);
+    if (dma_check(e, "esc_linear_bwd_both") != hipSuccess) return ESC_ELAUNCH;
+    const int64_t n = N * K;
+    if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, a.dw.db_part, N, db); return ESC_OK; }
+    esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+                splits, (int)K, dW, ld_dw, a.dw.db_part, (int)N, db);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_both.reduce");
     return ESC_OK;
   }
   if (dX == nullptr || N <= 32 || K <= 32) {             // other narrow shapes keep their dedicated tiles
