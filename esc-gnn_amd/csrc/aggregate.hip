@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
                                                     const int* __restrict__ in_src,
                                                     const float* __restrict__ eps_p, int N, int C,
                                                     float* __restrict__ out, int64_t ld_out) {
+  ESC_PRIO();
   const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   if (node >= N) return;
   const int lane = lane_id();
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void agg_fwd_elem(const float* __restrict__ x,
                                                     const int* __restrict__ in_src,
                                                     const float* __restrict__ eps_p, int N, int C,
                                                     float* __restrict__ out, int64_t ld_out) {
+  ESC_PRIO();
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)N * C) return;
   const int node = (int)(t / C), c = (int)(t % C);
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
                                                     float* __restrict__ d_e, int64_t ld_de,
                                                     float* __restrict__ dx, int64_t ld_dx, int accumulate_dx,
                                                     float* __restrict__ deps_part) {
+  ESC_PRIO();
   const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   if (node >= N) return;
   const int lane = lane_id();
@@ -221,6 +224,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void segment_pool_fwd(const float* __restrict__ x, int64_t ld_x,
                                                         const int* __restrict__ seg_ptr, int G, int C, int mean,
                                                         float* __restrict__ out, int64_t ld_out) {
+  ESC_PRIO();
   const int gidx = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   if (gidx >= G) return;
   const int lane = lane_id();
@@ -256,6 +260,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void segment_pool_bwd(const float* __restrict__ g, int64_t ld_g,
                                                         const int* __restrict__ seg_ptr, int G, int C, int mean,
                                                         float* __restrict__ dx, int64_t ld_dx) {
+  ESC_PRIO();
   const int gidx = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   if (gidx >= G) return;
   const int lane = lane_id();
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(256) void segment_pool_bwd(const float* __restrict_
 // deterministic single-block sum of n floats -> out[0] (fp64 accumulation)
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ v, int64_t n,
                                                           float* __restrict__ out) {
+  ESC_PRIO();
   __shared__ double sh[16];
   double acc = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double)v[i];
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restric
 // several independent sums in one launch: workgroup j reduces job j exactly like reduce_sum_kernel
 struct SumJobs { esc_sum_job job[ESC_MAX_SUM_JOBS]; };
 __global__ __launch_bounds__(1024) void reduce_sum_jobs_kernel(SumJobs t) {
+  ESC_PRIO();
   __shared__ double sh[16];
   const esc_sum_job& q = t.job[blockIdx.x];
   double acc = 0.0;

@@ -12,6 +12,15 @@ namespace esc {
 
 constexpr int WAVE = 64;  // CDNA4 wavefront
 
+// Instruction-issue priority of every kernel except the edge-sized GEMM tiles.  The step engine runs two pipelines on
+// two streams; the edge pipeline's 128x128 GEMM workgroups hold every CU for 20-50 us, and a co-resident kernel of the
+// latency-critical node chain loses the (age-ordered) issue arbitration to them: measured 25 us for an 8 us node GEMM.
+// Raising the priority of the short kernels lets them cut through; the big tiles soak up what is left.
+#ifndef ESC_NODE_PRIO
+#define ESC_NODE_PRIO 2
+#endif
+#define ESC_PRIO() __builtin_amdgcn_s_setprio(ESC_NODE_PRIO)
+
 void set_error(const char* fmt, ...);
 
 #define ESC_REQUIRE(cond, ...)                    \

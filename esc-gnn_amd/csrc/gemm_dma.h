@@ -84,7 +84,7 @@ struct GArgs {
   int red_per_split;                 // multiple of BK; splits = ceil(R / red_per_split)
   int accumulate;                    // C += ...
   int c_vec;                         // set by the launcher: 16-byte row stores are legal
-  int ntile_m, ntile_n;              // set by the launcher
+  int ntile_m, ntile_n, total_wg;    // set by the launcher
   unsigned long long* stamps;        // diagnostics (tools/gemm_lab): per workgroup clock readings, or null
 };
 
@@ -219,6 +219,8 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   float* pro = lds + C_::RING_FLOATS;     // PRO 1: [scale R | shift R]
   if constexpr (PRO == 1) {
     for (int k = threadIdx.x; k < g.R; k += C_::NTHR) { pro[k] = g.pro_scale[k]; pro[C_::PRO_MAXK + k] = g.pro_shift[k]; }
+    // the raw s_barrier of the first K-step publishes these writes: they must have LANDED before this wave arrives there
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   float cs[NT], ch_[NT];                  // PRO 2: this lane's column coefficients (column = lane & 31 of each block)
   if constexpr (PRO == 2) {
@@ -467,19 +469,27 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_kernel(GArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  gemm_body<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>(g, lds, (int)blockIdx.x);
+  if constexpr (BM * BN < 128 * 128) ESC_PRIO();            // node-sized tiles: see common.h
+  // grid < tiles (esc_tune_set(12, cap)): every workgroup walks several tiles, the launch occupies at most `cap` CUs
+  for (int wg = (int)blockIdx.x; wg < g.total_wg; wg += (int)gridDim.x) {
+    gemm_body<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>(g, lds, wg);
+    __syncthreads();                                          // the staging image is read until the tile's last store
+  }
 }
 
 // Backward of one Linear in ONE launch: the first workgroups compute the dX tiles (NN), the rest the split-M dW slabs
 // (TN).  Both stream the same dY; one launch instead of two removes a boundary and lets the two under-filled grids
 // of the node-sized layers share the chip.
-struct DualArgs { GArgs dx, dw; int n_dx; };
+struct DualArgs { GArgs dx, dw; int n_dx, total_wg; };
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_dual_kernel(DualArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int b = (int)blockIdx.x;
-  if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>(a.dx, lds, b);
-  else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>(a.dw, lds, b - a.n_dx);
+  if constexpr (BM * BN < 128 * 128) ESC_PRIO();
+  for (int b = (int)blockIdx.x; b < a.total_wg; b += (int)gridDim.x) {
+    if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>(a.dx, lds, b);
+    else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>(a.dw, lds, b - a.n_dx);
+    __syncthreads();
+  }
 }
 
 inline int splits_of(const GArgs& g) { return g.red_per_split >= g.R ? 1 : (int)cdiv(g.R, g.red_per_split); }
@@ -503,7 +513,7 @@ inline void finish_args(GArgs& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
-inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
+inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR, int wg_cap = 0) {
   using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
   auto kern = gemm_kernel<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
   const size_t lds = C_::LDS_BYTES > lds_floor ? C_::LDS_BYTES : lds_floor;
@@ -511,13 +521,14 @@ inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind
   hipError_t e = raise_lds(kern, lds, raised_to);
   if (e != hipSuccess) return e;
   finish_args<BM, BN>(g);
-  const unsigned nwg = (unsigned)(g.ntile_m * g.ntile_n * splits_of(g));
+  g.total_wg = g.ntile_m * g.ntile_n * splits_of(g);
+  const unsigned nwg = (unsigned)(wg_cap > 0 && wg_cap < g.total_wg ? wg_cap : g.total_wg);
   esc::launch(kind, kern, dim3(nwg), dim3(C_::NTHR), lds, s, g);
   return hipSuccess;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
-inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
+inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR, int wg_cap = 0) {
   using CX = Cfg<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>;
   using CW = Cfg<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>;
   auto kern = gemm_dual_kernel<BM, BN, BK, WM, WN, STAGES, LW, PRO>;
@@ -529,7 +540,8 @@ inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int k
   finish_args<BM, BN>(a.dx);
   finish_args<BM, BN>(a.dw);
   a.n_dx = a.dx.ntile_m * a.dx.ntile_n;
-  const unsigned nwg = (unsigned)(a.n_dx + a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw));
+  a.total_wg = a.n_dx + a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw);
+  const unsigned nwg = (unsigned)(wg_cap > 0 && wg_cap < a.total_wg ? wg_cap : a.total_wg);
   esc::launch(kind, kern, dim3(nwg), dim3(CX::NTHR), lds, s, a);
   return hipSuccess;
 }

@@ -22,6 +22,7 @@
 // consecutive banks).
 #include "common.h"
 #include "gemm_dma.h"
+#include "linear_small.h"
 #include <type_traits>
 
 namespace esc {
@@ -542,6 +543,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, float* __restr
 
 template <int BM, int BN, int WM, int WN, int BK, bool A_KC, bool B_KC, bool PRO, bool DB, int KW = 1>
 __global__ __launch_bounds__(WM * WN * KW * 64) void gemm_tile_kernel(GemmArgs g) {
+  ESC_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   gemm_tile_body<BM, BN, WM, WN, BK, A_KC, B_KC, PRO, DB, KW>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -552,6 +554,7 @@ __global__ __launch_bounds__(WM * WN * KW * 64) void gemm_tile_kernel(GemmArgs g
 struct DualArgs { GemmArgs dx; GemmArgs dw; int dx_nx, dx_ny, dw_nx, dw_ny, dw_nz; };
 template <int BM, int BN, int WM, int WN, int BK, bool PRO>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bwd_dual_kernel(DualArgs a) {
+  ESC_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x;
   const int n_dx = a.dx_nx * a.dx_ny;
@@ -570,6 +573,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           int cols, float* __restrict__ out, int64_t ld_out,
                                                           const float* __restrict__ db_part, int rows,
                                                           float* __restrict__ db) {
+  ESC_PRIO();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     float s = 0.f;
@@ -593,36 +597,64 @@ struct ReduceJobs {
   int count;
 };
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceJobs t) {
+  ESC_PRIO();
+  __shared__ float4 part[3][64];
   int j = 0;
   while (j + 1 < t.count && (int)blockIdx.x >= t.block_start[j + 1]) ++j;
   const esc_reduce_job& q = t.job[j];
-  const int64_t i = (int64_t)(blockIdx.x - t.block_start[j]) * blockDim.x + threadIdx.x;
-  const int64_t nw = t.vec[j] ? q.n / 4 : q.n;             // work items that cover the weight gradient
-  if (i < nw) {
-    if (t.vec[j]) {
+  const int blk = (int)blockIdx.x - t.block_start[j];
+  if (t.vec[j]) {
+    // a workgroup owns 64 consecutive gradient quads; its four waves each add a quarter of the slabs (in split order,
+    // 8 reads in flight), wave 0 then adds the four shares in wave order: a fixed association, bitwise reproducible.
+    // (One thread per quad walking all 60 slabs of an edge-sized gradient left 64 workgroups on the chip: 24 us.)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t nq = q.n / 4;
+    const int64_t nblk = (nq + 63) / 64;                    // blocks that cover the weight gradient
+    if (blk < nblk) {
+      const int64_t i = (int64_t)blk * 64 + lane;
+      const int per = (q.splits + 3) / 4;
+      const int k0 = w * per, k1 = min(q.splits, k0 + per);
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      int k = 0;
-      for (; k + 8 <= q.splits; k += 8) {        // 8 slab reads in flight per thread, added in split order
-        float4 v[8];
+      if (i < nq) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+          float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q.slabs + (size_t)(k + u) * q.n + 4 * i);
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q.slabs + (size_t)(k + u) * q.n + 4 * i);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+          for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < k1; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(q.slabs + (size_t)k * q.n + 4 * i);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
       }
-      for (; k < q.splits; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(q.slabs + (size_t)k * q.n + 4 * i);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      if (w > 0) part[w - 1][lane] = s;
+      __syncthreads();
+      if (w == 0 && i < nq) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { const float4 o = part[p][lane]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        const int64_t e = 4 * i;
+        *reinterpret_cast<float4*>(q.dw + (e / q.cols) * q.ld_dw + (e % q.cols)) = s;
       }
-      const int64_t e = 4 * i;
-      *reinterpret_cast<float4*>(q.dw + (e / q.cols) * q.ld_dw + (e % q.cols)) = s;
-    } else {
-      float s = 0.f;
-#pragma unroll 4
-      for (int k = 0; k < q.splits; ++k) s += q.slabs[(size_t)k * q.n + i];
-      q.dw[(i / q.cols) * q.ld_dw + (i % q.cols)] = s;
+    } else if (q.db != nullptr) {
+      const int64_t r = (int64_t)(blk - nblk) * 256 + threadIdx.x;
+      if (r < q.rows) {
+        float s = 0.f;
+        for (int k = 0; k < q.splits; ++k) s += q.db_part[(size_t)k * q.rows + r];
+        q.db[r] = s;
+      }
     }
-  } else if (q.db != nullptr && i - nw < q.rows) {
-    const int64_t r = i - nw;
+    return;
+  }
+  const int64_t i = (int64_t)blk * blockDim.x + threadIdx.x;
+  if (i < q.n) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < q.splits; ++k) s += q.slabs[(size_t)k * q.n + i];
+    q.dw[(i / q.cols) * q.ld_dw + (i % q.cols)] = s;
+  } else if (q.db != nullptr && i - q.n < q.rows) {
+    const int64_t r = i - q.n;
     float s = 0.f;
     for (int k = 0; k < q.splits; ++k) s += q.db_part[(size_t)k * q.rows + r];
     q.db[r] = s;
@@ -702,6 +734,7 @@ __global__ __launch_bounds__(256) void linear_narrow_fwd(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ sc, const float* __restrict__ sh,
                                                          int M, int N, int K, float* __restrict__ Y, int64_t ldy) {
+  ESC_PRIO();
   const int lane = lane_id();
   const int k = lane * 4;
   const bool valid = k < K;
@@ -753,6 +786,7 @@ __global__ __launch_bounds__(256) void linear_narrow_bwd(const float* __restrict
                                                          int M, int N, int K, float* __restrict__ dX, int64_t lddx,
                                                          int accumulate, float* __restrict__ slab,
                                                          float* __restrict__ db_part) {
+  ESC_PRIO();
   __shared__ float4 red[3][64];
   __shared__ float redb[3][NMAX];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -838,6 +872,7 @@ template <int NMAX>
 __global__ __launch_bounds__(256) void linear_narrow_dx(const float* __restrict__ dY, int64_t lddy,
                                                         const float* __restrict__ W, int64_t ldw, int M, int N, int K,
                                                         float* __restrict__ dX, int64_t lddx, int accumulate) {
+  ESC_PRIO();
   const int lane = lane_id();
   const int k = lane * 4;
   if (k >= K) return;
@@ -885,6 +920,8 @@ static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128, 2};
 // ---- dispatch to the LDS-DMA family (gemm_dma.h): the H-wide layers ---------------------------------------------
 // knob 11 (default 1): 0 keeps every GEMM on the r01 register-staged tiles above (A/B runs in one process)
 static int g_use_dma = 1;
+// knob 12 (default 0 = one workgroup per tile): workgroup cap of the EDGE-sized launches, which then walk their tiles
+static int g_edge_wg_cap = 0;
 static inline bool dma_ok(const void* p, int64_t rows, int64_t ld) {
   return aligned16(p) && ld % 4 == 0 && rows * ld * 4 < (1LL << 31);
 }
@@ -907,15 +944,18 @@ static void dma_wgrad_plan(int64_t M, int64_t N, int64_t K, int bm, int bn, int*
 static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias, const float* in_scale,
                     const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y, float* col_stats,
                     hipStream_t s, int* rc) {
-  if (!g_use_dma || K % 32 != 0 || N <= 32 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && K > 1280)) return false;
+  if (!g_use_dma || K % 32 != 0 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && K > 1280)) return false;
+  if (N <= 32 && (col_stats != nullptr || in_scale != nullptr)) return false;
   dma::GArgs g{};
   g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.col_stats = reinterpret_cast<float2*>(col_stats);
   g.M = (int)M; g.N = (int)N; g.R = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
   hipError_t e;
-  if (M >= 8192 && N >= 128) {     // edge-sized: 128x128 tile, 4 compute + 4 loader waves, one workgroup per CU
-    e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s)
-                 : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
+  if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
+    e = dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
+  } else if (M >= 8192 && N >= 128) {     // edge-sized: 128x128 tile, 4 compute + 4 loader waves, one workgroup per CU
+    e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
+                 : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s, ESC_K_LINEAR, g_edge_wg_cap);
   } else {                         // node-sized: 64x64 tile, 4 compute + 2 loader waves
     e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 1, true, false>(g, 0, s)
                  : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 0, true, false>(g, 0, s);
@@ -974,6 +1014,7 @@ int esc_tune_set(int knob, int value) {
   if (knob == 9) { set_norm_rowblock_cap(value); return ESC_OK; }
   if (knob == 10) { set_edge_lds_floor(value); return ESC_OK; }
   if (knob == 11) { g_use_dma = value != 0; return ESC_OK; }
+  if (knob == 12) { g_edge_wg_cap = value < 0 ? 0 : value; return ESC_OK; }
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
   g_knob[knob] = value;
   return ESC_OK;
@@ -1003,6 +1044,14 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
 #undef ESC_NARROW_FWD
     ESC_CHECK_LAUNCH("esc_linear_fwd.narrow");
     return ESC_OK;
+  }
+  if (g_use_dma && K <= small::SMALL_MAX && in_scale == nullptr && N > 32) {     // in_dim-wide inputs: see linear_small.h
+    esc::launch(ESC_K_LINEAR, small::smallk_fwd<small::SMALL_MAX>, dim3((unsigned)cdiv(M, small::ROWS_FWD), (unsigned)cdiv(N, 256)),
+                dim3(256), 0, s, X, ld_x, W, ld_w, bias, (int)M, (int)N, (int)K, Y, ld_y, reinterpret_cast<float2*>(col_stats));
+    ESC_CHECK_LAUNCH("esc_linear_fwd.smallk");
+    if (bn == nullptr) return ESC_OK;
+    return esc_bn_stats_from_partials(col_stats, M, N, bn->eps, bn->momentum, bn->mean, bn->invstd, bn->running_mean,
+                                      bn->running_var, bn->gamma, bn->beta, bn->scale, bn->shift, stream);
   }
   if (bn == nullptr || M > FUSE_FINALIZE_MAX_ROWS || !last_block_finalize()) {
     int rc = ESC_OK;
@@ -1075,10 +1124,19 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
     ESC_CHECK_LAUNCH("esc_linear_bwd_input.narrow");
     return ESC_OK;
   }
+  if (g_use_dma && K <= small::SMALL_MAX && N % 4 == 0 && N <= 1024 && aligned16(dY) && ld_dy % 4 == 0) {
+    const size_t lds = (size_t)(32 + small::SMALL_MAX) * (N + 4) * sizeof(float);
+    static size_t raised_to = 64 * 1024;
+    if (dma_check(dma::raise_lds(small::smalln_dx<small::SMALL_MAX>, lds, raised_to), "esc_linear_bwd_input") != hipSuccess) return ESC_ELAUNCH;
+    esc::launch(ESC_K_LINEAR, small::smalln_dx<small::SMALL_MAX>, dim3((unsigned)cdiv(M, 32)), dim3(256), lds, s, dY, ld_dy, W, ld_w,
+                (int)M, (int)N, (int)K, dX, ld_dx, accumulate);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_input.smalln");
+    return ESC_OK;
+  }
   if (dma_bwd_ok(dY, ld_dy, nullptr, 0, W, ld_w, M, N, K, dX, ld_dx, nullptr, true, false)) {
     dma::GArgs d{};
     dma_fill_dx(d, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
-    const hipError_t e = M >= 8192 ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s)
+    const hipError_t e = M >= 8192 ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
                                    : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, true, 0, false, false>(d, 0, s);
     return dma_check(e, "esc_linear_bwd_input") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
   }
@@ -1147,14 +1205,31 @@ static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t l
   ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_weight: dimension too large");
   hipStream_t s = (hipStream_t)stream;
   int splits, per;
+  if (g_use_dma && (K <= small::SMALL_MAX) != (N <= small::SMALL_MAX)) {        // one tiny feature dimension: linear_small.h
+    splits = (int)cdiv(M, small::ROWS_WGRAD);
+    float* db_part = slabs + (size_t)splits * N * K;
+    const bool small_k = K <= small::SMALL_MAX;
+    const dim3 grid((unsigned)splits, (unsigned)cdiv(small_k ? N : K, 256));
+#define ESC_WGRAD_SMALL(SK, PR) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, SK, PR>, grid, dim3(256), 0, s, dY, ld_dy, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part)
+    if (small_k) { if (in_scale) ESC_WGRAD_SMALL(true, true); else ESC_WGRAD_SMALL(true, false); }
+    else         { if (in_scale) ESC_WGRAD_SMALL(false, true); else ESC_WGRAD_SMALL(false, false); }
+#undef ESC_WGRAD_SMALL
+    ESC_CHECK_LAUNCH("esc_linear_bwd_weight.small");
+    const int64_t n = N * K;
+    if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, db_part, N, db); return ESC_OK; }
+    esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+                splits, (int)K, dW, ld_dw, db_part, (int)N, db);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_weight.reduce");
+    return ESC_OK;
+  }
   if (dma_bwd_ok(dY, ld_dy, X, ld_x, nullptr, 0, M, N, K, nullptr, 0, slabs, false, true)) {
     const bool big = M >= 8192;
     dma_wgrad_plan(M, N, K, big ? 128 : 64, big ? 128 : 64, &splits, &per);
     dma::GArgs d{};
     dma_fill_dw(d, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
     hipError_t e;
-    if (big) e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 2, false, true>(d, 0, s)
-                          : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 0, false, true>(d, 0, s);
+    if (big) e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 2, false, true>(d, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
+                          : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 0, false, true>(d, 0, s, ESC_K_LINEAR, g_edge_wg_cap);
     else     e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, true, true, 2, false, true>(d, 0, s)
                           : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, true, true, 0, false, true>(d, 0, s);
     if (dma_check(e, "esc_linear_bwd_weight") != hipSuccess) return ESC_ELAUNCH;
@@ -1247,7 +1322,7 @@ int esc_slab_reduce_jobs(const esc_reduce_job* jobs, int count, void* stream) {
     const esc_reduce_job& q = jobs[j];
     const bool vec = q.n % 4 == 0 && q.cols % 4 == 0 && q.ld_dw % 4 == 0 && aligned16(q.slabs) && aligned16(q.dw);
     t.vec[j] = vec ? 1 : 0;
-    blocks += (int)cdiv((vec ? q.n / 4 : q.n) + (q.db ? q.rows : 0), 256);
+    blocks += vec ? (int)(cdiv(q.n / 4, 64) + (q.db ? cdiv(q.rows, 256) : 0)) : (int)cdiv(q.n + (q.db ? q.rows : 0), 256);
   }
   t.block_start[count] = blocks;
   esc::launch(ESC_K_LINEAR, slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
@@ -1291,7 +1366,8 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
     dma_fill_dx(a.dx, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
     dma_fill_dw(a.dw, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
     hipError_t e;
-    if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false>(a, 0, s);
+    if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
+                          : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false>(a, 0, s, ESC_K_LINEAR, g_edge_wg_cap);
     else     e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false>(a, 0, s);
     if (dma_check(e, "esc_linear_bwd_both") != hipSuccess) return ESC_ELAUNCH;
     const int64_t n = N * K;

@@ -34,6 +34,7 @@ __device__ __forceinline__ float act_grad_from_pre(float v, int act) {
 // slot p owns rows p, p+P, p+2P, ...   partial[(p*C + c)] = {mean, M2}
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ X, int64_t ld, int M, int C,
                                                          float2* __restrict__ partial) {
+  ESC_PRIO();
   const int c = blockIdx.x * 64 + lane_id();
   const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int P = gridDim.y * 4;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // edge-sized tensors.
 __global__ __launch_bounds__(256) void bn_partial_kernel_v4(const float* __restrict__ X, int64_t ld, int M, int C,
                                                             float2* __restrict__ partial) {
+  ESC_PRIO();
   const int c = (blockIdx.x * 64 + lane_id()) * 4;
   const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int P = gridDim.y * 4;
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __r
                                                                 float2* partial, unsigned* tickets,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float2* __restrict__ coef) {
+  ESC_PRIO();
   constexpr int relu = ACT;
   __shared__ float4 sh[3][2][64];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restri
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  ESC_PRIO();
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (c >= C) return;
   const int lane = lane_id();
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int relu,
                                                        float* __restrict__ Y, int64_t ldy) {
+  ESC_PRIO();
   const int cv = C / VEC;
   const int64_t total = M * cv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              float2* __restrict__ partial) {
+  ESC_PRIO();
   const int c = blockIdx.x * 64 + lane_id();
   const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int P = gridDim.y * 4;
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __re
                                                               int P, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta,
                                                               float2* __restrict__ coef) {
+  ESC_PRIO();
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // one wave per column
   if (c >= C) return;
   const int lane = lane_id();
@@ -314,6 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            const float2* __restrict__ coef,
                                                            float* __restrict__ dX, int64_t ldd) {
+  ESC_PRIO();
   constexpr int relu = ACT;
   const int cv = C / VEC;
   const int64_t total = M * cv;
@@ -368,6 +376,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
                                                          const float* __restrict__ beta,
                                                          const float2* __restrict__ coef,
                                                          float* __restrict__ dX, int64_t ldd) {
+  ESC_PRIO();
   constexpr int relu = ACT;
   const int c = (blockIdx.x * 64 + lane_id()) * 4;
   if (c >= C) return;
@@ -404,6 +413,7 @@ __global__ __launch_bounds__(256) void affine_act_rows(const float* __restrict__
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu,
                                                        float* __restrict__ Y, int64_t ldy) {
+  ESC_PRIO();
   const int c = (blockIdx.x * 64 + lane_id()) * 4;
   if (c >= C) return;
   const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -424,6 +434,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int relu,
                                                          float* __restrict__ Y, int64_t ldy) {
+  ESC_PRIO();
   const int cv = C / VEC;
   const int64_t total = M * cv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -447,6 +458,7 @@ __global__ __launch_bounds__(256) void bn_eval_coef_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int C,
                                                            float* __restrict__ scale, float* __restrict__ shift) {
+  ESC_PRIO();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float sc = (gamma ? gamma[c] : 1.f) * (1.0f / sqrtf(rv[c] + eps));

@@ -10,6 +10,7 @@ namespace esc {
 __global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ y,
                                                        int64_t M, double denom, float grad_scale,
                                                        float* __restrict__ loss, float* __restrict__ dpred) {
+  ESC_PRIO();
   __shared__ double sh[16];
   double acc = 0.0;
   const float gs = (float)((double)grad_scale / denom);
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__
 __global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restrict__ pred, const float* __restrict__ y,
                                                           int64_t M, double denom_in, float* __restrict__ loss,
                                                           float* __restrict__ dpred) {
+  ESC_PRIO();
   __shared__ double sh[16];
   __shared__ double shc[16];
   double acc = 0.0, cnt = 0.0;
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float one_minus_b1, float b2, float one_minus_b2,
                                                    float bc2_sqrt, float eps, float neg_step,
                                                    const float* __restrict__ grad_denom) {
+  ESC_PRIO();
   // grad_denom (device scalar, may be null): the all-reduced bucket holds SUMS over the global batch; dividing
   // here saves a pass over the bucket (same rounding as grad.div_(total) followed by the plain update)
   const float den = grad_denom ? grad_denom[0] : 1.f;

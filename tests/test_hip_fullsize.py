@@ -283,8 +283,11 @@ def test_engine_matches_autograd_over_shapes(E, L, H, bs):
     assert abs(float(loss) - float(lt.detach())) <= 1e-5 * max(1.0, abs(float(lt.detach())))
     tw = dict(twin.named_parameters())
     for n, p in m.named_parameters():
+        # Frobenius 1e-3, as in the full-size test above: the two paths tile their GEMMs differently, and ONE pre-activation
+        # within fp32 rounding of a ReLU kink flipping between them moves every upstream gradient by a few 1e-4 relative
+        # (measured at L=5, bs=40 against the fp64 oracle: engine 1e-6, autograd path 4.5e-4, fp32 CPU oracle 6.4e-4)
         g = tw[n].grad
-        assert float((p.grad - g).norm()) <= 2e-4 * float(g.norm()) + 1e-6, n
+        assert float((p.grad - g).norm()) <= 1e-3 * float(g.norm()) + 1e-6, n
     # the same step through `model(batch)` + a torch loss + autograd (the reference's own loop, run_graphcount.py:494-503)
     for _ in range(2):
         node.zero_grad(set_to_none=True)
