@@ -31,6 +31,13 @@ class BnFuse(ctypes.Structure):
         "mean", "invstd", "running_mean", "running_var", "gamma", "beta", "scale", "shift")]
 
 
+class BnFold(ctypes.Structure):
+    """mirror of `esc_bn_fold` (include/escgnn_hip.h): a BatchNorm still in partial form, merged by its consumer"""
+    _fields_ = [("partials", c_void_p), ("rows", c_int64), ("block_rows", c_int64), ("C", c_int64),
+                ("eps", c_float), ("momentum", c_float)] + [(n, c_void_p) for n in (
+        "gamma", "beta", "mean", "invstd", "scale", "shift", "running_mean", "running_var")]
+
+
 # name -> argtypes (every function returns int unless listed in _RET)
 SIGNATURES = {
     "esc_abi_version": [],
@@ -51,6 +58,12 @@ SIGNATURES = {
     "esc_segment_pool_bwd": [P, I64, P, I64, I64, I32, P, I64, P],
     "esc_linear_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
     "esc_linear_bn_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, POINTER(BnFuse), P],
+    "esc_linear_stats_block_rows": [P, I64, P, I64, I64, I64, I64],
+    "esc_linear_fold_available": [],
+    "esc_engine_phase_times": [POINTER(c_double), I32],
+    "esc_linear_fwd_fold": [P, I64, P, I64, P, POINTER(BnFold), I64, I64, I64, P, I64, P, P],
+    "esc_bn_stats_from_partials_rows": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P],
+    "esc_affine_act_fold": [P, I64, I64, I64, POINTER(BnFold), I32, P, I64, P],
     "esc_tune_set": [I32, I32],
     "esc_debug_gemm_occupancy": [I32],
     "esc_linear_bwd_input": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
@@ -88,7 +101,7 @@ SIGNATURES = {
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
-_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64,
+_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64}
 

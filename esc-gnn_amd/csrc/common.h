@@ -130,4 +130,58 @@ __device__ __forceinline__ void chan_merge(double& n, double& mu, double& m2, do
   n = tot;
 }
 
+
+// ---- BatchNorm statistics consumed in place --------------------------------------------------------------------------
+// A forward GEMM leaves per-row-block (mean, M2) partials of its output columns; a separate finalize launch costs the
+// latency-critical node chain ~6 us per BatchNorm (13 per training step).  Instead the CONSUMER of the normalised value
+// merges the partials in its own prologue — every workgroup redundantly, in the same fixed order, so all of them see
+// bit-identical coefficients — and workgroup 0 stores what the backward pass and the running statistics need.
+struct BnFoldDev {
+  const float2* partials;     // [P][C]; partial p covers rows [p*block_rows, min(M, (p+1)*block_rows))
+  int P, block_rows, M, C;
+  float eps, momentum;
+  const float* gamma; const float* beta;            // may be null
+  float* mean; float* invstd; float* scale; float* shift; float* running_mean; float* running_var;   // outputs (writer only)
+};
+// Division-free merge of the equal-size groups around the first group's mean (fp64: no cancellation), then one Chan
+// merge with the ragged last group.  Sequential in p: a fixed order.
+__device__ __forceinline__ void bn_fold_column(const BnFoldDev& f, int col, bool writer, float& sc, float& sh) {
+  const int full = f.M / f.block_rows;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  if (full > 0) {
+    const double pivot = (double)f.partials[col].x;
+    double S1 = 0.0, S2 = 0.0, SM = 0.0;
+    // the partials were written by other workgroups: every load is an L2 / Infinity-Cache round trip, so ALL of a
+    // chunk's loads are issued before the first is consumed (38 partials for 2 400 rows: one round trip, not five)
+    constexpr int CH = 40;
+    for (int p0 = 0; p0 < full; p0 += CH) {
+      float2 v[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) v[u] = f.partials[(size_t)min(p0 + u, full - 1) * f.C + col];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        if (p0 + u < full) { const double d = (double)v[u].x - pivot; S1 += d; S2 += d * d; SM += (double)v[u].y; }
+      }
+    }
+    n = (double)f.block_rows * full;
+    mu = pivot + S1 / full;
+    m2 = SM + (double)f.block_rows * (S2 - S1 * S1 / full);
+    if (m2 < 0.0) m2 = 0.0;
+  }
+  if (f.M > f.block_rows * full) {
+    const float2 v = f.partials[(size_t)full * f.C + col];
+    chan_merge(n, mu, m2, (double)(f.M - f.block_rows * full), (double)v.x, (double)v.y);
+  }
+  const float is = (float)(1.0 / sqrt(m2 / (double)f.M + (double)f.eps));
+  sc = (f.gamma ? f.gamma[col] : 1.f) * is;
+  sh = (f.beta ? f.beta[col] : 0.f) - (float)mu * sc;
+  if (writer) {
+    f.mean[col] = (float)mu;
+    f.invstd[col] = is;
+    if (f.scale) { f.scale[col] = sc; f.shift[col] = sh; }
+    if (f.running_mean) f.running_mean[col] = (1.f - f.momentum) * f.running_mean[col] + f.momentum * (float)mu;
+    if (f.running_var) f.running_var[col] = (1.f - f.momentum) * f.running_var[col] + f.momentum * (float)(m2 / (double)(f.M - 1));
+  }
+}
+
 }  // namespace esc

@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include <vector>
+#include <cstdlib>
 
 namespace esc {
 
@@ -43,6 +44,7 @@ struct Layout {
   float* d_e[ESC_MAX_LAYERS];      // one per GINE layer: the edge stream consumes d_e[l] while the node chain moves on
   float *bn_scratch, *bag_scratch, *slabs;
   float *col_stats;               // GEMM-epilogue BatchNorm partials: float2[ceil(rows/32)][H]
+  float *col_stats_b;             // second set: a folded BatchNorm's partials live until its consumer has run
   // private scratch of the x_embedding branch (runs on a side stream next to the z/conv chain)
   float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
   float *bn_scratch_e, *col_stats_e;   // the edge stream's own BatchNorm scratch / GEMM-epilogue partials
@@ -71,6 +73,7 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   y.bn_scratch = a.take(esc_bn_scratch(H));
   y.bn_scratch_x = a.take(esc_bn_scratch(H));
   y.col_stats = a.take(2 * ((E > N ? E : N) / 32 + 1) * H);
+  y.col_stats_b = a.take(2 * (N / 32 + 1) * H);
   y.bn_scratch_e = a.take(esc_bn_scratch(H));
   y.col_stats_e = a.take(2 * (E / 32 + 1) * H);
   if (train) {
@@ -222,8 +225,36 @@ static Ctx side_ctx(const Ctx& c, hipStream_t side) {
   return x;
 }
 
+// ---- phase marks (diagnostics, ESC_PHASE_TIMING=1): timing-enabled events at fixed points of the two pipelines, kept in a
+// ring and read only by esc_engine_phase_times() after the caller has synchronised — no host/device sync inside the loop.
+enum { PH_START = 0, PH_EDGE_FWD_DONE, PH_NODE_FWD_DONE, PH_NODE_BWD_DONE, PH_EDGE_BWD_DONE, PH_END, PH_COUNT };
+struct PhaseRing {
+  static constexpr int RING = 128;
+  hipEvent_t ev[RING][PH_COUNT] = {};
+  int steps = 0;
+  bool on = getenv("ESC_PHASE_TIMING") != nullptr;
+};
+static PhaseRing& phases() { static PhaseRing p; return p; }
+static void mark(int which, void* stream) {
+  PhaseRing& p = phases();
+  if (!p.on) return;
+  hipEvent_t& e = p.ev[p.steps % PhaseRing::RING][which];
+  if (e == nullptr && hipEventCreate(&e) != hipSuccess) { p.on = false; return; }
+  (void)hipEventRecord(e, (hipStream_t)stream);
+}
+
 static int g_fuse_finalize = 1; // ... and their merge by the GEMM's last workgroup (no bn_finalize launch)
 static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's epilogue (no extra pass over Y)
+// Node-sized BatchNorms: partials merged in the consumer's prologue instead of a finalize launch (esc_engine_set_gemm_stats
+// bit 2 / ESC_BN_FOLD=1).  Measured on MI355X (cfg1, untraced, same box): 1.154 ms with it vs 1.144 ms without — with the
+// host running ahead a finalize launch costs the node chain ~5 us, and so does the redundant merge in every consumer
+// workgroup (77 KB of partials + 38 fp64 merges: GEMM 8.5 -> 13.3 us, affine pass 4.4 -> 10 us).  Off by default.
+static int g_fold = getenv("ESC_BN_FOLD") ? 1 : 0;
+
+static esc_bn_fold make_fold(const float* partials, int64_t rows, int64_t block_rows, int64_t C, const esc_bn_t& bn, const BnWs& w) {
+  return esc_bn_fold{partials, rows, block_rows, C, bn.eps, bn.momentum, bn.gamma, bn.beta, w.mean, w.invstd, w.scale, w.shift,
+                     bn.running_mean, bn.running_var};
+}
 
 // Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
 static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linear_t& lin, const float* sc, const float* sh,
@@ -237,8 +268,9 @@ static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linea
   }
   ESC_TRY(esc_linear_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, fused ? c.y.col_stats : nullptr, c.s));
   if (fused)
-    return esc_bn_stats_from_partials(c.y.col_stats, M, H, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean,
-                                      bn.running_var, bn.gamma, bn.beta, w.scale, w.shift, c.s);
+    return esc_bn_stats_from_partials_rows(c.y.col_stats, M, H, esc_linear_stats_block_rows(X, ld_x, lin.w, K, M, H, K), bn.eps,
+                                           bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma, bn.beta,
+                                           w.scale, w.shift, c.s);
   if (c.train)
     return esc_bn_stats(Y, H, M, H, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma,
                         bn.beta, w.scale, w.shift, c.y.bn_scratch, c.s);
@@ -254,9 +286,24 @@ static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const 
 }
 
 // Linear, BN, ReLU, Linear, BN, ReLU  (reference :65-73, :78-87) -> out (materialised, ld_out)
+// node-sized training-mode MLPs: no finalize launches — each BatchNorm's partials are merged by its consumer
+static bool fold_ok(const Ctx& c, int64_t M) {
+  const int64_t H = c.y.H;
+  return c.train && g_fold && g_gemm_stats && esc_linear_fold_available() && c.jobs != nullptr && !c.on_edge_stream && M > 1 && M <= 4096 && H % 32 == 0 &&
+         H > 32 && H <= 1024;
+}
+
 static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
                        float* out, int64_t ld_out) {
   const int64_t H = c.y.H;
+  if (fold_ok(c, M)) {
+    const int64_t K0 = p.lin0.in_dim;
+    ESC_TRY(esc_linear_fwd(A, ld_a, p.lin0.w, K0, p.lin0.b, nullptr, nullptr, M, H, K0, w.Y0, H, c.y.col_stats, c.s));
+    const esc_bn_fold f0 = make_fold(c.y.col_stats, M, esc_linear_stats_block_rows(A, ld_a, p.lin0.w, K0, M, H, K0), H, p.bn0, w.b0);
+    ESC_TRY(esc_linear_fwd_fold(w.Y0, H, p.lin1.w, H, p.lin1.b, &f0, M, H, H, w.Y1, H, c.y.col_stats_b, c.s));
+    const esc_bn_fold f1 = make_fold(c.y.col_stats_b, M, esc_linear_stats_block_rows(w.Y0, H, p.lin1.w, H, M, H, H), H, p.bn1, w.b1);
+    return esc_affine_act_fold(w.Y1, H, M, H, &f1, 1, out, ld_out, c.s);
+  }
   ESC_TRY(linear_bn(c, A, ld_a, p.lin0, nullptr, nullptr, M, w.Y0, p.bn0, w.b0));
   ESC_TRY(linear_bn(c, w.Y0, H, p.lin1, w.b0.scale, w.b0.shift, M, w.Y1, p.bn1, w.b1));
   return esc_affine_act(w.Y1, H, M, H, w.b1.scale, w.b1.shift, 1, out, ld_out, c.s);
@@ -312,6 +359,7 @@ static int forward(const Ctx& c) {
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     return ESC_OK;
   };
+  mark(PH_START, c.s);
   const int ahead = es.ok ? g_edge_ahead : (int)L;          // one stream: all of them up front, in layer order
   for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
   // ---- node pipeline (first, while it would otherwise wait for the first edge term: the chunk schedule of the bag
@@ -344,10 +392,16 @@ static int forward(const Ctx& c) {
     }
     ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W));
   }
+  if (c.train) mark(PH_EDGE_FWD_DONE, ce.s);
   // readout (reference :183-189) needs every slice of cat, including the side stream's
   if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_f, 0) != hipSuccess) {
     set_error("esc_engine: side-stream join failed");
     return ESC_ELAUNCH;
+  }
+  if (fold_ok(c, N) && H <= 256) {          // lin2 (a wave per row, H <= 256) merges bn_lin1's partials itself
+    ESC_TRY(esc_linear_fwd(y.cat, W, m->lin1.w, W, m->lin1.b, nullptr, nullptr, N, H, W, y.Yl, H, c.y.col_stats, c.s));
+    const esc_bn_fold f = make_fold(c.y.col_stats, N, esc_linear_stats_block_rows(y.cat, W, m->lin1.w, W, N, H, W), H, m->bn_lin1, y.bl);
+    return esc_linear_fwd_fold(y.Yl, H, m->lin2.w, H, m->lin2.b, &f, N, 1, H, y.pred, 1, nullptr, c.s);
   }
   ESC_TRY(linear_bn(c, y.cat, W, m->lin1, nullptr, nullptr, N, y.Yl, m->bn_lin1, y.bl));
   return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
@@ -373,6 +427,8 @@ static int finish_pending(Pending& p) {
   if (p.join && hipStreamWaitEvent(p.stream, es.joined, 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
   if (!p.edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(p.edge_jobs.data(), (int)p.edge_jobs.size(), p.stream));
   p.edge_jobs.clear();
+  mark(PH_END, p.stream);
+  if (phases().on) ++phases().steps;
   return ESC_OK;
 }
 
@@ -468,6 +524,8 @@ static int backward(const Ctx& c, Pending* defer) {
                      y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, ce.y.bn_scratch, ce.s));
   ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E,
                                  1, m->dz_table, y.bag_scratch, ce.s));
+  mark(PH_NODE_BWD_DONE, c.s);
+  mark(PH_EDGE_BWD_DONE, ce.s);
   // node-side reductions first (with an edge stream they overlap its tail), then join, then the edge-side ones
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
@@ -512,8 +570,39 @@ int esc_engine_set_side_stream(int on) {
   return ESC_OK;
 }
 
+/* diagnostics: mean milliseconds between the phase marks of the last recorded steps (ESC_PHASE_TIMING=1); call after a
+ * device synchronise.  out[0..5]: start->edge-forward done, start->node-forward done, node-forward done->node-backward done,
+ * node-backward done->edge-backward done (negative: the edge pipeline finished first), start->end of step, end->next start */
+int esc_engine_phase_times(double* out, int skip) {
+  PhaseRing& p = phases();
+  for (int i = 0; i < 6; ++i) out[i] = 0.0;
+  if (!p.on || p.steps < 2) return 0;
+  const int first = p.steps > PhaseRing::RING ? p.steps - PhaseRing::RING + 1 : 0;
+  int n = 0;
+  for (int sidx = first + skip; sidx < p.steps; ++sidx) {
+    hipEvent_t* e = p.ev[sidx % PhaseRing::RING];
+    bool ok = true;
+    for (int k = 0; k < PH_COUNT; ++k) ok = ok && e[k] != nullptr;
+    if (!ok) continue;
+    float t[6] = {};
+    if (hipEventElapsedTime(&t[0], e[PH_START], e[PH_EDGE_FWD_DONE]) != hipSuccess) continue;
+    (void)hipEventElapsedTime(&t[1], e[PH_START], e[PH_NODE_FWD_DONE]);
+    (void)hipEventElapsedTime(&t[2], e[PH_NODE_FWD_DONE], e[PH_NODE_BWD_DONE]);
+    if (hipEventElapsedTime(&t[3], e[PH_NODE_BWD_DONE], e[PH_EDGE_BWD_DONE]) != hipSuccess) {
+      (void)hipEventElapsedTime(&t[3], e[PH_EDGE_BWD_DONE], e[PH_NODE_BWD_DONE]); t[3] = -t[3];
+    }
+    (void)hipEventElapsedTime(&t[4], e[PH_START], e[PH_END]);
+    if (sidx + 1 < p.steps) (void)hipEventElapsedTime(&t[5], e[PH_END], p.ev[(sidx + 1) % PhaseRing::RING][PH_START]);
+    for (int i = 0; i < 6; ++i) out[i] += t[i];
+    ++n;
+  }
+  for (int i = 0; i < 6; ++i) out[i] /= n > 0 ? n : 1;
+  return n;
+}
+
 int esc_engine_set_gemm_stats(int on) {
   g_fuse_finalize = (on & 2) == 0;       // bit 1: keep the statistics epilogue but finalize in a separate launch
+  g_fold = (on & 4) != 0;                // bit 2: node-sized BatchNorms are merged by their consumers (see g_fold)
   g_gemm_stats = (on & 1) != 0;
   return ESC_OK;
 }
@@ -557,6 +646,7 @@ static int train_step_impl(const esc_nested_gin_t* m, const esc_batch_t* b, floa
   if (3 * m->num_layers + 7 <= ESC_MAX_REDUCE_JOBS) { c.jobs = &jobs; c.slab_cursor = &cursor; }
   ESC_TRY(forward(c));
   ESC_TRY(esc_l1_loss(c.y.pred, b->y, b->N, loss_denom > 0 ? loss_denom : b->N, 1.0f, loss, c.y.dpred, stream));
+  mark(PH_NODE_FWD_DONE, stream);
   if (pred) {
     if (hipMemcpyAsync(pred, c.y.pred, sizeof(float) * (size_t)b->N, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
       set_error("esc_engine_train_step: prediction copy failed");

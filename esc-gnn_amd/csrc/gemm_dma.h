@@ -77,14 +77,16 @@ struct GArgs {
   float* C; int ldc;                 // [M, N]; with splits > 1: slabs [split][M][N] (ldc = N)
   const float* bias;                 // [N] or null
   const float* pro_scale;            // PRO 1: [R] on A (KC)   PRO 2: [N] on B (RM):  x := relu(x * scale + shift)
+                                     // PRO 3: as 1, the coefficients merged from `fold` by every workgroup itself
   const float* pro_shift;
-  float2* col_stats;                 // [ceil(M/32)][N] (mean, M2) of the outputs, or null (STATS)
+  float2* col_stats;                 // [ceil(M/BM)][N] (mean, M2) of the outputs per ROW TILE, or null (STATS)
+  BnFoldDev fold;                    // PRO 3: the BatchNorm in front of A, still as partials (merged in the prologue)
   float* db_part;                    // DB: per-split sums over the reduction of A's columns, [split][M]
   int M, N, R;                       // output rows, output cols, reduction length
   int red_per_split;                 // multiple of BK; splits = ceil(R / red_per_split)
   int accumulate;                    // C += ...
   int c_vec;                         // set by the launcher: 16-byte row stores are legal
-  int ntile_m, ntile_n, total_wg;    // set by the launcher
+  int ntile_m, ntile_n;              // set by the launcher
   unsigned long long* stamps;        // diagnostics (tools/gemm_lab): per workgroup clock readings, or null
 };
 
@@ -113,15 +115,17 @@ struct Cfg {
   static constexpr int PPWA = PA / DW, PPWB = PB / DW, PPW = PPWA + PPWB;
   static constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
   static constexpr int OUT_LD = BN + 4, OUT_FLOATS = BM * OUT_LD;       // epilogue staging image [BM][BN+4]
-  static constexpr int RING_FLOATS = STAGES * STAGE_FLOATS > OUT_FLOATS ? STAGES * STAGE_FLOATS : OUT_FLOATS;
+  static constexpr int STAT_FLOATS = STATS ? WM * BN * 3 : 0;           // (n, mean, M2) per wave row and column
+  static constexpr int RING_FLOATS = STAGES * STAGE_FLOATS > OUT_FLOATS + STAT_FLOATS ? STAGES * STAGE_FLOATS : OUT_FLOATS + STAT_FLOATS;
   static constexpr int PRO_MAXK = 1280;
-  static constexpr int PRO_FLOATS = PRO == 1 ? 2 * PRO_MAXK : 0;        // scale | shift of the whole reduction range
+  static constexpr bool PRO_A = PRO == 1 || PRO == 3;                   // per-k affine + ReLU on a KC A operand
+  static constexpr int PRO_FLOATS = PRO_A ? 2 * PRO_MAXK : 0;           // scale | shift of the whole reduction range
   static constexpr size_t LDS_BYTES = (size_t)(RING_FLOATS + PRO_FLOATS) * 4;
   static constexpr int C4 = BN / 4;                                     // float4 per output row of the tile
   static_assert(PA % DW == 0 && PB % DW == 0, "pieces must split evenly over the DMA waves");
   static_assert(MT >= 1 && NT >= 1 && STAGES >= 2 && STAGES <= 4, "bad tile");
   static_assert(NTHR % C4 == 0, "a thread keeps one column quad through the epilogue");
-  static_assert(PRO == 0 || (PRO == 1 && !A_RM) || (PRO == 2 && B_RM), "prologue: per-k on a KC A, or per-column on an RM B");
+  static_assert(PRO == 0 || (PRO_A && !A_RM) || (PRO == 2 && B_RM), "prologue: per-k on a KC A, or per-column on an RM B");
   static_assert(!DB || A_RM, "bias gradient = column sums of a reduction-major A");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
 };
@@ -216,7 +220,15 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
       if (s < nk) stage(s);
   }
 
-  float* pro = lds + C_::RING_FLOATS;     // PRO 1: [scale R | shift R]
+  float* pro = lds + C_::RING_FLOATS;     // PRO 1 / 3: [scale R | shift R]
+  if constexpr (PRO == 3) {               // merge the producer's BatchNorm partials here (see common.h); tile 0 keeps the results
+    for (int k = threadIdx.x; k < g.R; k += C_::NTHR) {
+      float sc, sh;
+      bn_fold_column(g.fold, k, wg == 0, sc, sh);
+      pro[k] = sc; pro[C_::PRO_MAXK + k] = sh;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
   if constexpr (PRO == 1) {
     for (int k = threadIdx.x; k < g.R; k += C_::NTHR) { pro[k] = g.pro_scale[k]; pro[C_::PRO_MAXK + k] = g.pro_shift[k]; }
     // the raw s_barrier of the first K-step publishes these writes: they must have LANDED before this wave arrives there
@@ -278,17 +290,17 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
           bf[q][j] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
         }
       }
-      if constexpr (PRO == 1) {
+      if constexpr (C_::PRO_A) {
         const int k = red0 + kt * BK + c8 * 8 + h * 4;
         s4[q] = *reinterpret_cast<const float4*>(pro + k);
         h4[q] = *reinterpret_cast<const float4*>(pro + C_::PRO_MAXK + k);
       }
     };
-    constexpr int NREADS = (A_RM ? 4 : 1) * MT + (B_RM ? 4 : 1) * NT + (PRO == 1 ? 2 : 0);
-    constexpr int NVALU = PRO == 1 ? 8 * MT : (PRO == 2 ? 8 * NT : 0);
+    constexpr int NREADS = (A_RM ? 4 : 1) * MT + (B_RM ? 4 : 1) * NT + (C_::PRO_A ? 2 : 0);
+    constexpr int NVALU = C_::PRO_A ? 8 * MT : (PRO == 2 ? 8 * NT : 0);
     constexpr int NMFMA = 4 * MT * NT;
     auto transform = [&](int q) {         // consumer-side BatchNorm + ReLU on the staged operand
-      if constexpr (PRO == 1) {
+      if constexpr (C_::PRO_A) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           float4& v = af[q][i];
@@ -365,17 +377,20 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   }
   stamp(g.stamps, 2);
 
-  // ---- BatchNorm partials of the outputs (bias included): one (mean, M2) per column and 32-row block
+  // ---- BatchNorm partials of the outputs (bias included): one (mean, M2) per column and ROW TILE.  Each wave merges
+  // its MT 32-row blocks (registers); the WM wave rows meet through LDS between the two epilogue barriers.
+  float st_n[NT], st_mean[NT], st_m2[NT];
   if constexpr (STATS) {
     if (g.col_stats != nullptr && !loader) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * TN + j * 32 + lr;
+        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+        st_n[j] = 0.f; st_mean[j] = 0.f; st_m2[j] = 0.f;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int col = n0 + wn * TN + j * 32 + lr;
+        for (int i = 0; i < MT; ++i) {
           const int row0 = m0 + wm * TM + i * 32;
-          const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
-          const int nvalid = min(32, g.M - row0);
+          const int nvalid = max(0, min(32, g.M - row0));
           float mean, m2 = 0.f;
           if (nvalid >= 32) {             // interior block (wave-uniform): no row masks
             float s1 = 0.f;
@@ -401,8 +416,14 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
             }
           }
           m2 += __shfl_xor(m2, 32, 64);
-          if (l < 32 && col < g.N && nvalid > 0) g.col_stats[(size_t)(row0 / 32) * g.N + col] = make_float2(mean, m2);
+          if (nvalid > 0) {               // Chan merge (wave-uniform branch)
+            const float nb = (float)nvalid, tot = st_n[j] + nb, delta = mean - st_mean[j];
+            st_mean[j] += delta * (nb / tot);
+            st_m2[j] += m2 + delta * delta * (st_n[j] * nb / tot);
+            st_n[j] = tot;
+          }
         }
+      }
     }
   }
   if constexpr (DB) {
@@ -412,6 +433,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   // ---- epilogue: the tile is staged through LDS (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h) and
   // leaves as whole rows, 16 bytes per lane
   __syncthreads();                                           // everyone is done reading the last K tile
+  float* stat = lds + C_::OUT_FLOATS;                        // [WM][BN][3]
   if (!loader) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -420,8 +442,38 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           lds[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * C_::OUT_LD + wn * TN + j * 32 + lr] = acc[i][j][r];
+    if constexpr (STATS && WM > 1) {
+      if (g.col_stats != nullptr && wm > 0 && l < 32) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float* q = stat + (wm * BN + wn * TN + j * 32 + lr) * 3;
+          q[0] = st_n[j]; q[1] = st_mean[j]; q[2] = st_m2[j];
+        }
+      }
+    }
   }
   __syncthreads();
+  if constexpr (STATS) {
+    if (g.col_stats != nullptr && !loader && wm == 0 && l < 32) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * TN + j * 32 + lr;
+        float n = st_n[j], mean = st_mean[j], m2 = st_m2[j];
+#pragma unroll
+        for (int q = 1; q < WM; ++q) {                       // wave rows in order: a fixed association
+          const float* p = stat + (q * BN + wn * TN + j * 32 + lr) * 3;
+          const float nb = p[0];
+          if (nb > 0.f) {
+            const float tot = n + nb, delta = p[1] - mean;
+            mean += delta * (nb / tot);
+            m2 += p[2] + delta * delta * (n * nb / tot);
+            n = tot;
+          }
+        }
+        if (col < g.N && n > 0.f) g.col_stats[(size_t)(m0 / BM) * g.N + col] = make_float2(mean, m2);
+      }
+    }
+  }
   {
     constexpr int C4 = C_::C4, RPI = C_::NTHR / C4, ITERS = (BM + RPI - 1) / RPI;      // rows per pass, passes
     const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
@@ -470,26 +522,20 @@ template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM,
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_kernel(GArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if constexpr (BM * BN < 128 * 128) ESC_PRIO();            // node-sized tiles: see common.h
-  // grid < tiles (esc_tune_set(12, cap)): every workgroup walks several tiles, the launch occupies at most `cap` CUs
-  for (int wg = (int)blockIdx.x; wg < g.total_wg; wg += (int)gridDim.x) {
-    gemm_body<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>(g, lds, wg);
-    __syncthreads();                                          // the staging image is read until the tile's last store
-  }
+  gemm_body<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>(g, lds, (int)blockIdx.x);
 }
 
 // Backward of one Linear in ONE launch: the first workgroups compute the dX tiles (NN), the rest the split-M dW slabs
 // (TN).  Both stream the same dY; one launch instead of two removes a boundary and lets the two under-filled grids
 // of the node-sized layers share the chip.
-struct DualArgs { GArgs dx, dw; int n_dx, total_wg; };
+struct DualArgs { GArgs dx, dw; int n_dx; };
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_dual_kernel(DualArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if constexpr (BM * BN < 128 * 128) ESC_PRIO();
-  for (int b = (int)blockIdx.x; b < a.total_wg; b += (int)gridDim.x) {
-    if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>(a.dx, lds, b);
-    else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>(a.dw, lds, b - a.n_dx);
-    __syncthreads();
-  }
+  const int b = (int)blockIdx.x;
+  if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>(a.dx, lds, b);
+  else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>(a.dw, lds, b - a.n_dx);
 }
 
 inline int splits_of(const GArgs& g) { return g.red_per_split >= g.R ? 1 : (int)cdiv(g.R, g.red_per_split); }
@@ -513,7 +559,7 @@ inline void finish_args(GArgs& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
-inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR, int wg_cap = 0) {
+inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
   using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
   auto kern = gemm_kernel<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
   const size_t lds = C_::LDS_BYTES > lds_floor ? C_::LDS_BYTES : lds_floor;
@@ -521,14 +567,13 @@ inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind
   hipError_t e = raise_lds(kern, lds, raised_to);
   if (e != hipSuccess) return e;
   finish_args<BM, BN>(g);
-  g.total_wg = g.ntile_m * g.ntile_n * splits_of(g);
-  const unsigned nwg = (unsigned)(wg_cap > 0 && wg_cap < g.total_wg ? wg_cap : g.total_wg);
+  const unsigned nwg = (unsigned)(g.ntile_m * g.ntile_n * splits_of(g));
   esc::launch(kind, kern, dim3(nwg), dim3(C_::NTHR), lds, s, g);
   return hipSuccess;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
-inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR, int wg_cap = 0) {
+inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
   using CX = Cfg<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>;
   using CW = Cfg<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>;
   auto kern = gemm_dual_kernel<BM, BN, BK, WM, WN, STAGES, LW, PRO>;
@@ -540,8 +585,7 @@ inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int k
   finish_args<BM, BN>(a.dx);
   finish_args<BM, BN>(a.dw);
   a.n_dx = a.dx.ntile_m * a.dx.ntile_n;
-  a.total_wg = a.n_dx + a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw);
-  const unsigned nwg = (unsigned)(wg_cap > 0 && wg_cap < a.total_wg ? wg_cap : a.total_wg);
+  const unsigned nwg = (unsigned)(a.n_dx + a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw));
   esc::launch(kind, kern, dim3(nwg), dim3(CX::NTHR), lds, s, a);
   return hipSuccess;
 }

@@ -728,12 +728,13 @@ static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (l
 // =================================================================================================
 constexpr int NARROW_N = 4, NARROW_K = 256, NARROW_ROWS = 128;   // measured: at N = 10 the wave reductions cost more than the padded MFMA tile
 
-template <int NMAX, bool PRO>
+template <int NMAX, bool PRO, bool FOLD = false>
 __global__ __launch_bounds__(256) void linear_narrow_fwd(const float* __restrict__ X, int64_t ldx,
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ sc, const float* __restrict__ sh,
-                                                         int M, int N, int K, float* __restrict__ Y, int64_t ldy) {
+                                                         int M, int N, int K, float* __restrict__ Y, int64_t ldy,
+                                                         BnFoldDev fold) {
   ESC_PRIO();
   const int lane = lane_id();
   const int k = lane * 4;
@@ -743,7 +744,13 @@ __global__ __launch_bounds__(256) void linear_narrow_fwd(const float* __restrict
   for (int n = 0; n < NMAX; ++n)
     w[n] = (valid && n < N) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), ph = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (PRO) {
+  if constexpr (PRO && FOLD) {           // the BatchNorm in front of X is still in partial form: merge it here (common.h)
+    if (valid) {
+      const bool writer = blockIdx.x == 0 && threadIdx.x < 64;
+      bn_fold_column(fold, k + 0, writer, ps.x, ph.x); bn_fold_column(fold, k + 1, writer, ps.y, ph.y);
+      bn_fold_column(fold, k + 2, writer, ps.z, ph.z); bn_fold_column(fold, k + 3, writer, ps.w, ph.w);
+    }
+  } else if constexpr (PRO) {
     if (valid) { ps = *reinterpret_cast<const float4*>(sc + k); ph = *reinterpret_cast<const float4*>(sh + k); }
   }
   const float bv = (bias != nullptr && lane < N) ? bias[lane] : 0.f;
@@ -919,9 +926,7 @@ static int g_knob[KNOB_COUNT] = {1, 4, 1, 4, 4, 512, 128, 2};
 
 // ---- dispatch to the LDS-DMA family (gemm_dma.h): the H-wide layers ---------------------------------------------
 // knob 11 (default 1): 0 keeps every GEMM on the r01 register-staged tiles above (A/B runs in one process)
-static int g_use_dma = 1;
-// knob 12 (default 0 = one workgroup per tile): workgroup cap of the EDGE-sized launches, which then walk their tiles
-static int g_edge_wg_cap = 0;
+static int g_use_dma = 15;        // bit 0: forward, bit 1: gradients, bit 2: the tiny-dimension kernels (linear_small.h), bit 3: 64x32 narrow-output tile
 static inline bool dma_ok(const void* p, int64_t rows, int64_t ld) {
   return aligned16(p) && ld % 4 == 0 && rows * ld * 4 < (1LL << 31);
 }
@@ -944,8 +949,8 @@ static void dma_wgrad_plan(int64_t M, int64_t N, int64_t K, int bm, int bn, int*
 static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias, const float* in_scale,
                     const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y, float* col_stats,
                     hipStream_t s, int* rc) {
-  if (!g_use_dma || K % 32 != 0 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && K > 1280)) return false;
-  if (N <= 32 && (col_stats != nullptr || in_scale != nullptr)) return false;
+  if (!(g_use_dma & 1) || K % 32 != 0 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && K > 1280)) return false;
+  if (N <= 32 && (!(g_use_dma & 8) || col_stats != nullptr || in_scale != nullptr)) return false;
   dma::GArgs g{};
   g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.col_stats = reinterpret_cast<float2*>(col_stats);
@@ -954,8 +959,8 @@ static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, 
   if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
     e = dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
   } else if (M >= 8192 && N >= 128) {     // edge-sized: 128x128 tile, 4 compute + 4 loader waves, one workgroup per CU
-    e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
-                 : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s, ESC_K_LINEAR, g_edge_wg_cap);
+    e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s)
+                 : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
   } else {                         // node-sized: 64x64 tile, 4 compute + 2 loader waves
     e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 1, true, false>(g, 0, s)
                  : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 0, true, false>(g, 0, s);
@@ -966,7 +971,7 @@ static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, 
 static bool dma_bwd_ok(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* W, int64_t ld_w,
                        int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx, const float* slabs, bool need_dx,
                        bool need_dw) {
-  if (!g_use_dma || N <= 32 || K <= 32 || N % 4 != 0 || K % 4 != 0 || !dma_ok(dY, M, ld_dy)) return false;
+  if (!(g_use_dma & 2) || N <= 32 || K <= 32 || N % 4 != 0 || K % 4 != 0 || !dma_ok(dY, M, ld_dy)) return false;
   if (need_dx && (N % 32 != 0 || !dma_ok(W, N, ld_w) || !dma_ok(dX, M, ld_dx))) return false;
   if (need_dw && (!dma_ok(X, M, ld_x) || !aligned16(slabs))) return false;
   return true;
@@ -1013,8 +1018,7 @@ int esc_tune_set(int knob, int value) {
   if (knob == 8) { set_last_block_finalize(value); return ESC_OK; }
   if (knob == 9) { set_norm_rowblock_cap(value); return ESC_OK; }
   if (knob == 10) { set_edge_lds_floor(value); return ESC_OK; }
-  if (knob == 11) { g_use_dma = value != 0; return ESC_OK; }
-  if (knob == 12) { g_edge_wg_cap = value < 0 ? 0 : value; return ESC_OK; }
+  if (knob == 11) { g_use_dma = value; return ESC_OK; }
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);
   g_knob[knob] = value;
   return ESC_OK;
@@ -1038,27 +1042,28 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
   if (col_stats == nullptr && narrow_ok(N, K, X, ld_x, W, ld_w, in_scale, in_shift)) {
     const unsigned blocks = (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048);      // 4 rows per wave and pass
 #define ESC_NARROW_FWD(NM) \
-    if (in_scale) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y); \
-    else          esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, false>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y)
+    if (in_scale) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y, BnFoldDev{}); \
+    else          esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, false>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y, BnFoldDev{})
     if (N == 1) { ESC_NARROW_FWD(1); } else { ESC_NARROW_FWD(4); }
 #undef ESC_NARROW_FWD
     ESC_CHECK_LAUNCH("esc_linear_fwd.narrow");
     return ESC_OK;
   }
-  if (g_use_dma && K <= small::SMALL_MAX && in_scale == nullptr && N > 32) {     // in_dim-wide inputs: see linear_small.h
+  if ((g_use_dma & 4) && K <= small::SMALL_MAX && in_scale == nullptr && N > 32) {     // in_dim-wide inputs: see linear_small.h
     esc::launch(ESC_K_LINEAR, small::smallk_fwd<small::SMALL_MAX>, dim3((unsigned)cdiv(M, small::ROWS_FWD), (unsigned)cdiv(N, 256)),
                 dim3(256), 0, s, X, ld_x, W, ld_w, bias, (int)M, (int)N, (int)K, Y, ld_y, reinterpret_cast<float2*>(col_stats));
     ESC_CHECK_LAUNCH("esc_linear_fwd.smallk");
     if (bn == nullptr) return ESC_OK;
-    return esc_bn_stats_from_partials(col_stats, M, N, bn->eps, bn->momentum, bn->mean, bn->invstd, bn->running_mean,
-                                      bn->running_var, bn->gamma, bn->beta, bn->scale, bn->shift, stream);
+    return esc_bn_stats_from_partials_rows(col_stats, M, N, small::ROWS_FWD, bn->eps, bn->momentum, bn->mean, bn->invstd,
+                                           bn->running_mean, bn->running_var, bn->gamma, bn->beta, bn->scale, bn->shift, stream);
   }
   if (bn == nullptr || M > FUSE_FINALIZE_MAX_ROWS || !last_block_finalize()) {
     int rc = ESC_OK;
     if (dma_fwd(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, s, &rc)) {
       if (rc != ESC_OK || bn == nullptr) return rc;
-      return esc_bn_stats_from_partials(col_stats, M, N, bn->eps, bn->momentum, bn->mean, bn->invstd, bn->running_mean,
-                                        bn->running_var, bn->gamma, bn->beta, bn->scale, bn->shift, stream);
+      return esc_bn_stats_from_partials_rows(col_stats, M, N, (M >= 8192 && N >= 128) ? 128 : 64, bn->eps, bn->momentum, bn->mean,
+                                             bn->invstd, bn->running_mean, bn->running_var, bn->gamma, bn->beta, bn->scale,
+                                             bn->shift, stream);
     }
   }
   GemmArgs g{};
@@ -1096,6 +1101,44 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
   return ESC_OK;
 }
 
+int esc_linear_fold_available(void) { return (g_use_dma & 1) != 0; }
+
+int64_t esc_linear_stats_block_rows(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N,
+                                    int64_t K) {
+  if ((g_use_dma & 4) && K <= small::SMALL_MAX && N > 32) return small::ROWS_FWD;
+  if ((g_use_dma & 1) && K % 32 == 0 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w)) return (M >= 8192 && N >= 128) ? 128 : 64;
+  return 32;
+}
+
+int esc_linear_fwd_fold(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                        const esc_bn_fold* in_bn, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y,
+                        float* col_stats, void* stream) {
+  ESC_REQUIRE(X && W && Y && in_bn && in_bn->partials && in_bn->mean && in_bn->invstd, "esc_linear_fwd_fold: null pointer");
+  ESC_REQUIRE(M > 0 && N > 0 && K > 0 && ld_x >= K && ld_w >= K && ld_y >= N && M < (1LL << 31), "esc_linear_fwd_fold: bad sizes");
+  ESC_REQUIRE(in_bn->C == K && in_bn->rows > 1 && in_bn->block_rows > 0, "esc_linear_fwd_fold: the folded BatchNorm must have K channels");
+  ESC_REQUIRE((in_bn->scale == nullptr) == (in_bn->shift == nullptr), "esc_linear_fwd_fold: scale/shift must come together");
+  hipStream_t s = (hipStream_t)stream;
+  BnFoldDev f{reinterpret_cast<const float2*>(in_bn->partials), (int)cdiv(in_bn->rows, in_bn->block_rows), (int)in_bn->block_rows,
+              (int)in_bn->rows, (int)in_bn->C, in_bn->eps, in_bn->momentum, in_bn->gamma, in_bn->beta, in_bn->mean, in_bn->invstd,
+              in_bn->scale, in_bn->shift, in_bn->running_mean, in_bn->running_var};
+  if (col_stats == nullptr && N <= NARROW_N && K <= NARROW_K && K % 4 == 0 && vec_ok(X, ld_x) && vec_ok(W, ld_w)) {
+    const unsigned blocks = (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048);
+    if (N == 1) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<1, true, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, (const float*)nullptr, (const float*)nullptr, (int)M, (int)N, (int)K, Y, ld_y, f);
+    else        esc::launch(ESC_K_LINEAR, linear_narrow_fwd<4, true, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, (const float*)nullptr, (const float*)nullptr, (int)M, (int)N, (int)K, Y, ld_y, f);
+    ESC_CHECK_LAUNCH("esc_linear_fwd_fold.narrow");
+    return ESC_OK;
+  }
+  ESC_REQUIRE((g_use_dma & 1) && K % 32 == 0 && K <= 1280 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w),
+              "esc_linear_fwd_fold: shape not served by the folding kernels (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
+  dma::GArgs g{};
+  g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
+  g.col_stats = reinterpret_cast<float2*>(col_stats); g.fold = f;
+  g.M = (int)M; g.N = (int)N; g.R = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
+  const hipError_t e = (M >= 8192 && N >= 128) ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 3, true, false>(g, 0, s)
+                                               : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 3, true, false>(g, 0, s);
+  return dma_check(e, "esc_linear_fwd_fold") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
+}
+
 int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
                    const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                    float* Y, int64_t ld_y, float* col_stats, void* stream) {
@@ -1124,7 +1167,7 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
     ESC_CHECK_LAUNCH("esc_linear_bwd_input.narrow");
     return ESC_OK;
   }
-  if (g_use_dma && K <= small::SMALL_MAX && N % 4 == 0 && N <= 1024 && aligned16(dY) && ld_dy % 4 == 0) {
+  if ((g_use_dma & 4) && K <= small::SMALL_MAX && N % 4 == 0 && N <= 1024 && aligned16(dY) && ld_dy % 4 == 0) {
     const size_t lds = (size_t)(32 + small::SMALL_MAX) * (N + 4) * sizeof(float);
     static size_t raised_to = 64 * 1024;
     if (dma_check(dma::raise_lds(small::smalln_dx<small::SMALL_MAX>, lds, raised_to), "esc_linear_bwd_input") != hipSuccess) return ESC_ELAUNCH;
@@ -1136,7 +1179,7 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
   if (dma_bwd_ok(dY, ld_dy, nullptr, 0, W, ld_w, M, N, K, dX, ld_dx, nullptr, true, false)) {
     dma::GArgs d{};
     dma_fill_dx(d, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
-    const hipError_t e = M >= 8192 ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
+    const hipError_t e = M >= 8192 ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s)
                                    : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, true, 0, false, false>(d, 0, s);
     return dma_check(e, "esc_linear_bwd_input") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
   }
@@ -1175,7 +1218,9 @@ static void wgrad_plan_tile(int64_t M, int64_t N, int64_t K, int bm, int bn, int
 }
 
 int64_t esc_linear_bwd_weight_scratch(int64_t M, int64_t N, int64_t K) {
-  // upper bound over every tunable plan: at most ceil(M/128) splits
+  // upper bound over every tunable plan: at most ceil(M/128) splits; the tiny-dimension kernels (linear_small.h) cut the
+  // rows finer, their slabs are a few KB each
+  if ((K <= small::SMALL_MAX) != (N <= small::SMALL_MAX)) return (cdiv(M, small::ROWS_WGRAD) + 1) * (N * K + N);
   return (cdiv(M, 128) + 1) * (N * K + N);
 }
 
@@ -1205,7 +1250,7 @@ static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t l
   ESC_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "esc_linear_bwd_weight: dimension too large");
   hipStream_t s = (hipStream_t)stream;
   int splits, per;
-  if (g_use_dma && (K <= small::SMALL_MAX) != (N <= small::SMALL_MAX)) {        // one tiny feature dimension: linear_small.h
+  if ((g_use_dma & 4) && (K <= small::SMALL_MAX) != (N <= small::SMALL_MAX)) {        // one tiny feature dimension: linear_small.h
     splits = (int)cdiv(M, small::ROWS_WGRAD);
     float* db_part = slabs + (size_t)splits * N * K;
     const bool small_k = K <= small::SMALL_MAX;
@@ -1228,8 +1273,8 @@ static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t l
     dma::GArgs d{};
     dma_fill_dw(d, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
     hipError_t e;
-    if (big) e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 2, false, true>(d, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
-                          : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 0, false, true>(d, 0, s, ESC_K_LINEAR, g_edge_wg_cap);
+    if (big) e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 2, false, true>(d, 0, s)
+                          : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, true, true, 0, false, true>(d, 0, s);
     else     e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, true, true, 2, false, true>(d, 0, s)
                           : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, true, true, 0, false, true>(d, 0, s);
     if (dma_check(e, "esc_linear_bwd_weight") != hipSuccess) return ESC_ELAUNCH;
@@ -1366,8 +1411,8 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
     dma_fill_dx(a.dx, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
     dma_fill_dw(a.dw, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
     hipError_t e;
-    if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s, ESC_K_LINEAR, g_edge_wg_cap)
-                          : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false>(a, 0, s, ESC_K_LINEAR, g_edge_wg_cap);
+    if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s)
+                          : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false>(a, 0, s);
     else     e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false>(a, 0, s);
     if (dma_check(e, "esc_linear_bwd_both") != hipSuccess) return ESC_ELAUNCH;
     const int64_t n = N * K;

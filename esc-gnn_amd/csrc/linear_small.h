@@ -15,7 +15,7 @@ namespace small {
 
 constexpr int SMALL_MAX = 16;
 constexpr int ROWS_FWD = 32;          // rows per workgroup = rows per BatchNorm partial (the GEMM epilogue's contract)
-constexpr int ROWS_WGRAD = 128;       // reduction rows per slab
+constexpr int ROWS_WGRAD = 32;        // reduction rows per slab (a slab is N*K <= 16*1280 floats: hundreds of them are cheap to sum)
 
 // thread = output column n; the K weights of its column live in registers; X rows are workgroup-uniform scalars
 template <int KMAX>

@@ -24,6 +24,15 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
   if (act == 2) return y > 0.f ? 1.f : y + 1.f;
   return 1.f;
 }
+// The pre-activation exactly as the forward pass formed it (consumer-side fused BatchNorm: fmaf(x, scale, shift) with
+// scale = gamma*invstd, shift = beta - mean*scale, the same float expressions as bn_finalize / bn_fold_column): a mask
+// recomputed as ((x-mean)*invstd)*gamma+beta rounds differently, and an element within an ulp of the kink then gets a
+// gradient although the forward clipped it (or vice versa) — measured: a handful per 6*10^5 activations, each worth
+// ~1e-3 of relative gradient error at node size.
+__device__ __forceinline__ float pre_act_fwd(float x, float mu, float is, float ga, float be) {
+  const float sc = ga * is;
+  return fmaf(x, sc, be - mu * sc);
+}
 // ... or through the pre-activation v when the output was never materialised
 __device__ __forceinline__ float act_grad_from_pre(float v, int act) {
   if (act == 1) return v > 0.f ? 1.f : 0.f;
@@ -132,8 +141,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __r
           g.x *= act_grad_from_out(y.x, relu); g.y *= act_grad_from_out(y.y, relu);
           g.z *= act_grad_from_out(y.z, relu); g.w *= act_grad_from_out(y.w, relu);
         } else {
-          g.x *= act_grad_from_pre(fmaf(xh.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(fmaf(xh.y, ga.y, be.y), relu);
-          g.z *= act_grad_from_pre(fmaf(xh.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(fmaf(xh.w, ga.w, be.w), relu);
+          g.x *= act_grad_from_pre(pre_act_fwd(x.x, mu.x, is.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(pre_act_fwd(x.y, mu.y, is.y, ga.y, be.y), relu);
+          g.z *= act_grad_from_pre(pre_act_fwd(x.z, mu.z, is.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(pre_act_fwd(x.w, mu.w, is.w, ga.w, be.w), relu);
         }
       }
       s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
@@ -278,9 +287,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 #pragma unroll 4
   for (int r = slot; r < M; r += P) {
     float g = dY[(size_t)r * ldg + c];
-    const float xh = (X[(size_t)r * ldx + c] - mu) * is;
+    const float xv = X[(size_t)r * ldx + c];
+    const float xh = (xv - mu) * is;
     if (relu) {   // activation derivative from the forward output (if kept) or from the recomputed pre-activation
-      g *= Y ? act_grad_from_out(Y[(size_t)r * ldy + c], relu) : act_grad_from_pre(fmaf(xh, ga, be), relu);
+      g *= Y ? act_grad_from_out(Y[(size_t)r * ldy + c], relu) : act_grad_from_pre(pre_act_fwd(xv, mu, is, ga, be), relu);
     }
     s1 += g;
     s2 = fmaf(g, xh, s2);
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       float g = gv[t];
       if constexpr (ACT != 0) {
         if constexpr (HAS_Y) g *= act_grad_from_out(yv[t], relu);
-        else g *= act_grad_from_pre(fmaf(xh, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f), relu);
+        else g *= act_grad_from_pre(pre_act_fwd(xv[t], mean[c + t], is, gamma ? gamma[c + t] : 1.f, beta ? beta[c + t] : 0.f), relu);
       }
       const float2 k = coef[c + t];
       ov[t] = (gamma ? gamma[c + t] : 1.f) * is * (g - k.x - xh * k.y);
@@ -398,8 +408,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
         g.x *= act_grad_from_out(y.x, relu); g.y *= act_grad_from_out(y.y, relu);
         g.z *= act_grad_from_out(y.z, relu); g.w *= act_grad_from_out(y.w, relu);
       } else {
-        g.x *= act_grad_from_pre(fmaf(xh.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(fmaf(xh.y, ga.y, be.y), relu);
-        g.z *= act_grad_from_pre(fmaf(xh.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(fmaf(xh.w, ga.w, be.w), relu);
+        g.x *= act_grad_from_pre(pre_act_fwd(x.x, mu.x, is.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(pre_act_fwd(x.y, mu.y, is.y, ga.y, be.y), relu);
+        g.z *= act_grad_from_pre(pre_act_fwd(x.z, mu.z, is.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(pre_act_fwd(x.w, mu.w, is.w, ga.w, be.w), relu);
       }
     }
     // same expression as bn_bwd_apply_kernel: gamma * invstd * (g - k.x - xhat * k.y)
@@ -419,6 +429,31 @@ __global__ __launch_bounds__(256) void affine_act_rows(const float* __restrict__
   const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int P = gridDim.y * 4;
   const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+#pragma unroll 4
+  for (int r = slot; r < M; r += P) {
+    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
+    *reinterpret_cast<float4*>(Y + (size_t)r * ldy + c) =
+        make_float4(act_fwd(fmaf(x.x, sc.x, sh.x), relu), act_fwd(fmaf(x.y, sc.y, sh.y), relu),
+                    act_fwd(fmaf(x.z, sc.z, sh.z), relu), act_fwd(fmaf(x.w, sc.w, sh.w), relu));
+  }
+}
+
+// affine_act_rows with the BatchNorm still in partial form: every workgroup merges the partials of its column quad
+// (bn_fold_column, common.h), the first row block stores the coefficients for the backward pass
+__global__ __launch_bounds__(256) void affine_act_fold_rows(const float* __restrict__ X, int64_t ldx, int M, int C,
+                                                            BnFoldDev f, int relu, float* __restrict__ Y, int64_t ldy) {
+  ESC_PRIO();
+  __shared__ float coef[2][256];
+  // one column per thread for the merge (all its partial loads in flight at once), a column quad per lane afterwards
+  const int cm = blockIdx.x * 256 + threadIdx.x;
+  if (cm < C) bn_fold_column(f, cm, blockIdx.y == 0, coef[0][threadIdx.x], coef[1][threadIdx.x]);
+  __syncthreads();
+  const int lane = lane_id();
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  if (c >= C) return;
+  const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int P = gridDim.y * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(&coef[0][lane * 4]), sh = *reinterpret_cast<const float4*>(&coef[1][lane * 4]);
 #pragma unroll 4
   for (int r = slot; r < M; r += P) {
     const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
@@ -511,6 +546,38 @@ int esc_bn_stats_from_partials(const float* partials, int64_t M, int64_t C, floa
               (const float2*)partials, (int)M, (int)C, (int)cdiv(M, 32), 32, eps, momentum, mean, invstd, running_mean,
               running_var, gamma, beta, scale, shift);
   ESC_CHECK_LAUNCH("esc_bn_stats_from_partials");
+  return ESC_OK;
+}
+
+int esc_bn_stats_from_partials_rows(const float* partials, int64_t M, int64_t C, int64_t block_rows, float eps,
+                                    float momentum, float* mean, float* invstd, float* running_mean,
+                                    float* running_var, const float* gamma, const float* beta, float* scale,
+                                    float* shift, void* stream) {
+  ESC_REQUIRE(partials && mean && invstd, "esc_bn_stats_from_partials_rows: null pointer");
+  ESC_REQUIRE(M > 1 && C > 0 && M < (1LL << 31) && block_rows > 0, "esc_bn_stats_from_partials_rows: need more than 1 row per channel");
+  ESC_REQUIRE((scale == nullptr) == (shift == nullptr), "esc_bn_stats_from_partials_rows: scale/shift must come together");
+  esc::launch(ESC_K_NORM, bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream,
+              (const float2*)partials, (int)M, (int)C, (int)cdiv(M, block_rows), (int)block_rows, eps, momentum, mean, invstd,
+              running_mean, running_var, gamma, beta, scale, shift);
+  ESC_CHECK_LAUNCH("esc_bn_stats_from_partials_rows");
+  return ESC_OK;
+}
+
+int esc_affine_act_fold(const float* X, int64_t ld_x, int64_t M, int64_t C, const esc_bn_fold* bn, int relu, float* Y,
+                        int64_t ld_y, void* stream) {
+  ESC_REQUIRE(X && Y && bn && bn->partials && bn->mean && bn->invstd, "esc_affine_act_fold: null pointer");
+  ESC_REQUIRE(M > 1 && M < (1LL << 31) && C > 0 && C % 4 == 0 && bn->C == C && bn->rows > 1 && bn->block_rows > 0 && ld_x >= C && ld_y >= C &&
+              ld_x % 4 == 0 && ld_y % 4 == 0 && aligned16(X) && aligned16(Y), "esc_affine_act_fold: bad sizes / alignment");
+  ESC_REQUIRE((bn->scale == nullptr) == (bn->shift == nullptr), "esc_affine_act_fold: scale/shift must come together");
+  BnFoldDev f{reinterpret_cast<const float2*>(bn->partials), (int)cdiv(bn->rows, bn->block_rows), (int)bn->block_rows, (int)bn->rows,
+              (int)bn->C, bn->eps, bn->momentum, bn->gamma, bn->beta, bn->mean, bn->invstd, bn->scale, bn->shift,
+              bn->running_mean, bn->running_var};
+  // 32 rows per workgroup: every workgroup re-reads the partials (77 KB for 2 400 rows of 256 columns), so fewer and
+  // fatter workgroups than the plain affine pass
+  const unsigned rb = (unsigned)(cdiv(M, 32) < 1024 ? cdiv(M, 32) : 1024);
+  esc::launch(ESC_K_NORM, affine_act_fold_rows, dim3((unsigned)cdiv(C, 256), rb), dim3(256), 0, (hipStream_t)stream, X, ld_x,
+              (int)M, (int)C, f, relu, Y, ld_y);
+  ESC_CHECK_LAUNCH("esc_affine_act_fold");
   return ESC_OK;
 }
 

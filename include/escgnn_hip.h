@@ -100,9 +100,9 @@ int esc_reduce_sum_jobs(const esc_sum_job* jobs, int count, void* stream);
  * torch.nn.Linear call sites run_graphcount.py:54-121,183-189 (+ GINEConv.lin).
  * Y[M,N] = act(X)[M,K] * W[N,K]^T + bias[N]   (bias may be NULL)
  * act(X) = X, or relu(X*in_scale[k] + in_shift[k]) when in_scale != NULL (fused BN+ReLU of the
- * producer layer).  col_stats (may be NULL; needs N > 32): float2[ceil(M/32)][N] — per 32-row block the (mean, M2)
- * of every output column, written by the GEMM epilogue so that the BatchNorm that follows needs no pass over Y
- * (finish with esc_bn_stats_from_partials). */
+ * producer layer).  col_stats (may be NULL; needs N > 32): float2[ceil(M/R)][N] — per R-row block the (mean, M2)
+ * of every output column, R = esc_linear_stats_block_rows(...), written by the GEMM epilogue so that the BatchNorm
+ * that follows needs no pass over Y (finish with esc_bn_stats_from_partials_rows, or fold it into the consumer). */
 int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
                    const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                    float* Y, int64_t ld_y, float* col_stats, void* stream);
@@ -125,6 +125,34 @@ typedef struct esc_bn_fuse {
 int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
                       const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                       float* Y, int64_t ld_y, float* col_stats, const esc_bn_fuse* bn, void* stream);
+/* ---- BatchNorm statistics consumed in place ("fold") ----------------------------------------------------------
+ * The forward GEMM leaves one (mean, M2) partial per output column and ROW BLOCK in col_stats; the block height
+ * depends on the kernel that served the shape: esc_linear_stats_block_rows() (32, 64 or 128).  Finish them either with
+ * a finalize launch (esc_bn_stats_from_partials_rows) or — node-sized layers — inside the CONSUMER of the BatchNorm
+ * output: esc_linear_fwd_fold / esc_affine_act_fold merge the partials in their prologue (every workgroup in the same
+ * fixed order: bit-identical coefficients) and workgroup 0 stores mean / invstd / scale / shift and updates the running
+ * statistics.  One launch less per BatchNorm on the latency-critical chain (~6 us each, 11 per training step). */
+typedef struct esc_bn_fold {
+  const float* partials;     /* float2[ceil(rows/block_rows)][C] */
+  int64_t rows, block_rows, C;
+  float eps, momentum;
+  const float* gamma;        /* [C] or NULL (= 1) */
+  const float* beta;         /* [C] or NULL (= 0) */
+  float* mean;               /* [C] out */
+  float* invstd;             /* [C] out */
+  float* scale;              /* [C] out, may be NULL (together with shift) */
+  float* shift;
+  float* running_mean;       /* [C] in/out, may be NULL */
+  float* running_var;        /* [C] in/out, may be NULL */
+} esc_bn_fold;
+int64_t esc_linear_stats_block_rows(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N,
+                                    int64_t K);
+int esc_linear_fold_available(void);        /* 0 while esc_tune_set(11, 0) keeps every GEMM on the r01 tiles */
+/* Y = relu(BN(X)) W^T + bias with the BatchNorm of X still in partial form; K = in_bn->C <= 1280, K % 32 == 0 and
+ * 16-byte aligned rows (the H-wide layers), or N <= 4 (lin2).  ESC_EINVAL otherwise: finalize and call esc_linear_fwd. */
+int esc_linear_fwd_fold(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                        const esc_bn_fold* in_bn, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y,
+                        float* col_stats, void* stream);
 /* tile-shape / split knobs of the three GEMM forms (benchmark sweeps; defaults are the tuned ones):
  * 0 fwd tile for M>=8192, 1 fwd tile for small M, 2/3 same for dX, 4 dW tile, 5 dW target workgroups,
  * 6 dW minimum reduction rows per split (>=128), 7 node-sized fused-backward tile (0: 64x64xBK64, 1: 32x64xBK32 2-wave,
@@ -190,6 +218,13 @@ int esc_bn_stats_from_partials(const float* partials, int64_t M, int64_t C, floa
                                float* mean, float* invstd, float* running_mean, float* running_var,
                                const float* gamma, const float* beta, float* scale, float* shift,
                                void* stream);
+int esc_bn_stats_from_partials_rows(const float* partials, int64_t M, int64_t C, int64_t block_rows, float eps,
+                                    float momentum, float* mean, float* invstd, float* running_mean,
+                                    float* running_var, const float* gamma, const float* beta, float* scale,
+                                    float* shift, void* stream);
+/* Y = act(BN(X)) with the BatchNorm still in partial form (bn->C == C <= 1024, C % 4 == 0, 16-byte aligned rows) */
+int esc_affine_act_fold(const float* X, int64_t ld_x, int64_t M, int64_t C, const esc_bn_fold* bn, int relu, float* Y,
+                        int64_t ld_y, void* stream);
 int esc_bn_apply(const float* X, int64_t ld_x, int64_t M, int64_t C, const float* mean,
                  const float* invstd, const float* gamma, const float* beta, int relu, float* Y,
                  int64_t ld_y, void* stream);
@@ -279,6 +314,9 @@ int esc_engine_set_materialise_edge_act(int on);
 /* 1 (default): BatchNorm statistics come from the producing GEMM's epilogue (col_stats) and are merged by that
  * launch's last workgroups (esc_linear_bn_fwd); 3: same epilogue, separate finalize launch; 0: a pass over Y */
 int esc_engine_set_gemm_stats(int on);
+/* diagnostics (ESC_PHASE_TIMING=1 in the environment): mean ms between event marks of the two pipelines over the recorded
+ * steps; call after a device synchronise.  Returns the number of steps averaged. */
+int esc_engine_phase_times(double* out6, int skip_first);
 int64_t esc_engine_workspace_floats(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z);
 /* loss[0] = sum|pred-y| / loss_denom (loss_denom <= 0: N).  pred (may be NULL): float[N]. */
 int esc_engine_train_step(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace,

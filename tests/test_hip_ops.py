@@ -306,6 +306,78 @@ def test_linear_with_fused_batchnorm_statistics(E, M, N, K, last_block):
     _chk(rvd, 0.9 * rv0.double() + 0.1 * r.var(0, unbiased=True), "running_var")
 
 
+@pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (2401, 256, 10), (333, 64, 64), (15200, 256, 256), (97, 128, 1280)])
+def test_batchnorm_folded_into_its_consumer(E, M, N, K):
+    """esc_linear_fwd leaves BatchNorm partials (block height = esc_linear_stats_block_rows); the consumers merge them in
+    their prologue: esc_linear_fwd_fold (MFMA tile and the wave-per-row narrow form) and esc_affine_act_fold, against fp64
+    BatchNorm + ReLU.  Workgroup 0 must leave mean / invstd / scale / shift and the running statistics."""
+    import ctypes
+    nv = E._native
+    torch.manual_seed(M + N + K)
+    dev = torch.device("cuda:0")
+    x, w, bias = torch.randn(M, K) * 2 + 1, torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    gamma, beta = torch.rand(N) + 0.5, torch.randn(N)
+    rm0, rv0 = torch.randn(N), torch.rand(N) + 0.5
+    N2 = 256
+    w2, b2 = torch.randn(N2, N) / N ** 0.5, torch.randn(N2)
+    w3, b3 = torch.randn(1, N) / N ** 0.5, torch.randn(1)
+    xd, wd, bd, gd, btd = (t.to(dev).contiguous() for t in (x, w, bias, gamma, beta))
+    w2d, b2d, w3d, b3d = (t.to(dev).contiguous() for t in (w2, b2, w3, b3))
+    y = torch.empty(M, N, device=dev)
+    stats = torch.zeros(((M + 31) // 32) * N * 2, device=dev)
+    nv.call("esc_linear_fwd", nv.ptr(xd), K, nv.ptr(wd), K, nv.ptr(bd), None, None, M, N, K, nv.ptr(y), N, nv.ptr(stats), nv.stream())
+    br = nv.lib().esc_linear_stats_block_rows(nv.ptr(xd), K, nv.ptr(wd), K, M, N, K)
+    assert br in (32, 64, 128)
+    r = x.double() @ w.double().t() + bias.double()
+    mu, var = r.mean(0), r.var(0, unbiased=False)
+    sc = gamma.double() / torch.sqrt(var + 1e-5)
+    act = torch.relu(r * sc + (beta.double() - mu * sc))
+
+    def fold(with_running):
+        mean, invstd, scale, shift = (torch.full((N,), float("nan"), device=dev) for _ in range(4))
+        rmd, rvd = rm0.to(dev), rv0.to(dev)
+        f = nv.BnFold(nv.ptr(stats), M, br, N, 1e-5, 0.1, nv.ptr(gd), nv.ptr(btd), nv.ptr(mean), nv.ptr(invstd), nv.ptr(scale),
+                      nv.ptr(shift), nv.ptr(rmd) if with_running else None, nv.ptr(rvd) if with_running else None)
+        return f, (mean, invstd, scale, shift, rmd, rvd)
+
+    def check_outputs(o, with_running):
+        mean, invstd, scale, shift, rmd, rvd = o
+        _chk(mean, mu, "mean"); _chk(invstd, 1 / torch.sqrt(var + 1e-5), "invstd")
+        _chk(scale, sc, "scale"); _chk(shift, beta.double() - mu * sc, "shift")
+        if with_running:
+            _chk(rmd, 0.9 * rm0.double() + 0.1 * mu, "running_mean")
+            _chk(rvd, 0.9 * rv0.double() + 0.1 * r.var(0, unbiased=True), "running_var")
+
+    # 1. the elementwise consumer
+    f, o = fold(True)
+    out = torch.full((M, N), float("nan"), device=dev)
+    nv.call("esc_affine_act_fold", nv.ptr(y), N, M, N, ctypes.byref(f), 1, nv.ptr(out), N, nv.stream())
+    _chk(out, act, "affine_act_fold")
+    check_outputs(o, True)
+    # 2. the next Linear on the matrix cores (N % 32 == 0: every shape here), with its own statistics epilogue
+    f, o = fold(False)
+    y2 = torch.full((M, N2), float("nan"), device=dev)
+    stats2 = torch.zeros(((M + 31) // 32) * N2 * 2, device=dev)
+    nv.call("esc_linear_fwd_fold", nv.ptr(y), N, nv.ptr(w2d), N, nv.ptr(b2d), ctypes.byref(f), M, N2, N, nv.ptr(y2), N2,
+            nv.ptr(stats2), nv.stream())
+    r2 = act @ w2.double().t() + b2.double()
+    _chk(y2, r2, "linear_fwd_fold")
+    check_outputs(o, False)
+    br2 = nv.lib().esc_linear_stats_block_rows(nv.ptr(y), N, nv.ptr(w2d), N, M, N2, N)
+    m2, i2 = torch.empty(N2, device=dev), torch.empty(N2, device=dev)
+    nv.call("esc_bn_stats_from_partials_rows", nv.ptr(stats2), M, N2, br2, 1e-5, 0.1, nv.ptr(m2), nv.ptr(i2), None, None, None, None,
+            None, None, nv.stream())
+    _chk(m2, r2.mean(0), "mean of the folded layer's output")
+    _chk(i2, 1 / torch.sqrt(r2.var(0, unbiased=False) + 1e-5), "invstd of the folded layer's output")
+    # 3. the wave-per-row narrow form (lin2: H -> 1)
+    if N <= 256:
+        f, o = fold(False)
+        y3 = torch.full((M, 1), float("nan"), device=dev)
+        nv.call("esc_linear_fwd_fold", nv.ptr(y), N, nv.ptr(w3d), N, nv.ptr(b3d), ctypes.byref(f), M, 1, N, nv.ptr(y3), 1, None, nv.stream())
+        _chk(y3, act @ w3.double().t() + b3.double(), "narrow linear_fwd_fold")
+        check_outputs(o, False)
+
+
 @pytest.mark.parametrize("M,C", [(2400, 256), (50, 300), (4096, 64)])
 def test_batchnorm_backward_with_last_block_finalize(E, M, C):
     """knob 8: the BatchNorm-backward column sums are folded by the last workgroup of the partial kernel."""
