@@ -45,6 +45,7 @@ SIGNATURES = {
     "esc_prof_enable": [I32, I32],
     "esc_prof_read": [I32, POINTER(c_int64), POINTER(c_double)],
     "esc_prof_reset": [I32],
+    "esc_prof_read_all": [I32, POINTER(c_double), c_int64],
     "esc_bag_fwd": [P, I64, P, P, P, I64, P, I64, P],
     "esc_bag_bwd_scratch": [I64, I64],
     "esc_bag_bwd_table": [P, I64, I64, P, P, P, P, I64, I64, P, P, P],
@@ -101,7 +102,7 @@ SIGNATURES = {
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
-_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64,
+_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_prof_read_all": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64}
 
@@ -171,3 +172,10 @@ def prof_read(kind):
     n, ms = c_int64(0), c_double(0.0)
     call("esc_prof_read", KIND[kind], ctypes.byref(n), ctypes.byref(ms))
     return n.value, ms.value
+
+
+def prof_read_all(kind, cap=1 << 16):
+    """per-launch durations (ms) of the recorded launches of a kernel family, in launch order"""
+    buf = (c_double * cap)()
+    n = lib().esc_prof_read_all(KIND[kind], buf, cap)
+    return [buf[i] for i in range(n)]

@@ -116,4 +116,19 @@ int esc_prof_read(int kind, int64_t* launches, double* total_ms) {
   return ESC_OK;
 }
 
+/* per-launch durations (ms) of the recorded launches of `kind`, in launch order; returns how many were written */
+int64_t esc_prof_read_all(int kind, double* ms_out, int64_t cap) {
+  if (kind < 0 || kind >= ESC_K_COUNT || ms_out == nullptr || cap <= 0) return 0;
+  std::lock_guard<std::mutex> lk(esc::g_prof_mu);
+  esc::ProfState& p = esc::g_prof[kind];
+  int64_t n = 0;
+  for (size_t i = 0; i < p.used && n < cap; ++i) {
+    if (hipEventSynchronize(p.stop[i]) != hipSuccess) break;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, p.start[i], p.stop[i]);
+    ms_out[n++] = ms;
+  }
+  return n;
+}
+
 }  // extern "C"

@@ -35,7 +35,9 @@ const char* esc_last_error(void);         /* message of the last failing call on
 enum { ESC_K_AGG_FWD = 0, ESC_K_AGG_BWD = 1, ESC_K_BAG_FWD = 2, ESC_K_BAG_BWD = 3,
        ESC_K_LINEAR = 4, ESC_K_COLLATE = 5, ESC_K_FEATURES = 6, ESC_K_NORM = 7, ESC_K_COUNT = 8 };
 int esc_prof_enable(int kind, int on);    /* on!=0: bracket every launch of `kind` with events */
-int esc_prof_read(int kind, int64_t* launches, double* total_ms);  /* host; syncs recorded events */
+int esc_prof_read(int kind, int64_t* launches, double* total_ms);
+/* per-launch durations (ms) in launch order; returns the number written (<= cap) */
+int64_t esc_prof_read_all(int kind, double* ms_out, int64_t cap);  /* host; syncs recorded events */
 int esc_prof_reset(int kind);
 
 /* ---- a-6 ESC bag: z[k,:] = sum_j val_j * W[idx_j,:]  (run_graphcount.py:155) -------------
