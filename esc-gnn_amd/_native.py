@@ -65,6 +65,8 @@ SIGNATURES = {
     "esc_linear_fwd_fold": [P, I64, P, I64, P, POINTER(BnFold), I64, I64, I64, P, I64, P, P],
     "esc_bn_stats_from_partials_rows": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P],
     "esc_affine_act_fold": [P, I64, I64, I64, POINTER(BnFold), I32, P, I64, P],
+    "esc_plan_csr_scratch": [I64, I64],
+    "esc_plan_csr": [P, I64, I64, P, P, P, P, P],
     "esc_tune_set": [I32, I32],
     "esc_debug_gemm_occupancy": [I32],
     "esc_linear_bwd_input": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
@@ -102,7 +104,7 @@ SIGNATURES = {
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
-_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_prof_read_all": c_int64,
+_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_prof_read_all": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64}
 

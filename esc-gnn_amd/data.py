@@ -108,10 +108,14 @@ class Data(object):
         return self
 
     def to(self, device, non_blocking=False):
-        plan = object.__getattribute__(self, "__dict__").get("_esc_plan")
-        if plan is not None:
+        d = object.__getattribute__(self, "__dict__")
+        plan = d.get("_esc_plan")
+        out = self.apply(lambda t: t.to(device, non_blocking=non_blocking))
+        if plan is not None:                                 # the plan follows its tensors; re-key it on their new identity
+            from .plan import plan_key
             plan.to(device)
-        return self.apply(lambda t: t.to(device, non_blocking=non_blocking))
+            plan._key = plan_key(self, plan.n_cols)
+        return out
 
     def contiguous(self):
         return self.apply(lambda t: t.contiguous())

@@ -15,10 +15,19 @@ from ..plan import BatchPlan
 
 
 def _plans(multihop_edge_index, distance, k, num_nodes):
+    """One execution plan per distance class (esc_plan_csr, csrc/plan.hip).  They depend on the batch only, while every
+    GINE+ layer of the model asks for them: cached on the edge tensor, keyed on the identity (address, shape, in-place
+    version) of both inputs, so that L layers x forward/backward build them once per batch."""
+    from ..plan import _sig
+    key = (_sig(multihop_edge_index), _sig(distance), int(k), int(num_nodes))
+    cached = getattr(multihop_edge_index, "_esc_gineplus_plans", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
     out = []
     for d in range(1, k + 1):
         ei = multihop_edge_index[:, distance == d]
         out.append(BatchPlan.from_tensors(ei, num_nodes))
+    multihop_edge_index._esc_gineplus_plans = (key, out)
     return out
 
 

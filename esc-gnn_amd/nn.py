@@ -53,10 +53,6 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
                                                    self.eps, self.momentum, self.fuse_relu, self.sync_group)
             return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                       self.eps, self.momentum, self.fuse_relu)
-        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            y = torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
-                                               False, 0.0, self.eps)
-            return torch.relu(y) if self.fuse_relu == 1 else (torch.nn.functional.elu(y) if self.fuse_relu == 2 else y)
         return ops.bn_eval_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                self.fuse_relu)
 

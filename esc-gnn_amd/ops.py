@@ -300,17 +300,55 @@ def sync_batch_norm_act(x, gamma, beta, running_mean, running_var, eps, momentum
     return _SyncBatchNormAct.apply(x, gamma, beta, running_mean, running_var, eps, momentum, relu, group)
 
 
+class _BnEvalAct(Function):
+    """Inference-mode BatchNorm (+ fused activation) on the RUNNING statistics, differentiable: y = act(x*scale + shift)
+    with scale = gamma / sqrt(running_var + eps), shift = beta - running_mean*scale (model.eval() with gradients enabled:
+    fine-tuning with frozen statistics, input-gradient probes).  Backward on the BatchNorm kernels with the batch terms
+    switched off: column sums give d(gamma), d(beta); dx = scale * dy * act'(.)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, relu):
+        _dev(x)
+        _on(x.device, gamma, beta, running_mean, running_var)
+        x, ldx = _rows(x)
+        M, C = x.shape
+        dev = x.device
+        scale, shift = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        s = nv.stream()
+        nv.call("esc_bn_eval_coef", nv.ptr(running_mean), nv.ptr(running_var), nv.ptr(gamma), nv.ptr(beta), float(eps), C,
+                nv.ptr(scale), nv.ptr(shift), s)
+        y = torch.empty((M, C), dtype=torch.float32, device=dev)
+        if M > 0:
+            nv.call("esc_affine_act", nv.ptr(x), ldx, M, C, nv.ptr(scale), nv.ptr(shift), int(relu), nv.ptr(y), C, s)
+        ctx.save_for_backward(x, y if relu else None, gamma, beta, running_mean, running_var)
+        ctx.relu, ctx.eps = int(relu), float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, rm, rv = ctx.saved_tensors
+        dy, ldg = _rows(dy)
+        M, C = x.shape
+        dev = x.device
+        s = nv.stream()
+        invstd, unused = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        nv.call("esc_bn_eval_coef", nv.ptr(rm), nv.ptr(rv), None, None, ctx.eps, C, nv.ptr(invstd), nv.ptr(unused), s)
+        dx = torch.empty((M, C), dtype=torch.float32, device=dev)
+        dgamma, dbeta = torch.zeros(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev)
+        if M > 0:
+            scratch = torch.empty(nv.lib().esc_bn_scratch(C), dtype=torch.float32, device=dev)
+            sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            nv.call("esc_bn_bwd_sums", nv.ptr(x), x.stride(0), nv.ptr(y), C, nv.ptr(dy), ldg, M, C, nv.ptr(rm), nv.ptr(invstd),
+                    nv.ptr(gamma), nv.ptr(beta), ctx.relu, nv.ptr(sums), nv.ptr(dgamma), nv.ptr(dbeta), nv.ptr(scratch), s)
+            zero = torch.zeros(2 * C, dtype=torch.float32, device=dev)       # no batch-statistics terms in eval mode
+            nv.call("esc_bn_bwd_apply", nv.ptr(x), x.stride(0), nv.ptr(y), C, nv.ptr(dy), ldg, M, C, nv.ptr(rm), nv.ptr(invstd),
+                    nv.ptr(gamma), nv.ptr(beta), ctx.relu, nv.ptr(zero), nv.ptr(dx), C, s)
+        return dx, (dgamma if gamma is not None else None), (dbeta if beta is not None else None), None, None, None, None
+
+
 def bn_eval_act(x, gamma, beta, running_mean, running_var, eps, relu):
-    """Inference-mode BatchNorm (+ReLU) with running statistics — no autograd (eval/no_grad path)."""
-    _dev(x)
-    _on(x.device, gamma, beta, running_mean, running_var)
-    x, ldx = _rows(x)
-    M, C = x.shape
-    invstd = torch.rsqrt(running_var + eps)
-    y = torch.empty((M, C), dtype=torch.float32, device=x.device)
-    nv.call("esc_bn_apply", nv.ptr(x), ldx, M, C, nv.ptr(running_mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
-            int(relu), nv.ptr(y), C, nv.stream())
-    return y
+    """Inference-mode BatchNorm (+activation) with running statistics; differentiable (see _BnEvalAct)."""
+    return _BnEvalAct.apply(x, gamma, beta, running_mean, running_var, eps, relu)
 
 
 class _L1Loss(Function):

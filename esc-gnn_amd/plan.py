@@ -12,18 +12,31 @@ i.e. bit-identical to a sequential scatter).  User-visible tensors are never reo
   col_*  : bag entries grouped by histogram bin (table gradient)
 
 The fast path gets these from the device collate (DeviceGraphStore.collate); for a foreign batch
-they are derived here with torch sorts (host-side plumbing, once per batch).
+they are derived here by esc_plan_csr (csrc/plan.hip), once per batch and cached on the Data object.
 """
 import torch
 
 
-def _csr(key, n_keys):
-    """stable grouping of positions 0..len(key)-1 by key -> (ptr int32[n_keys+1], perm int32)."""
-    order = torch.sort(key, stable=True)[1]
-    counts = torch.bincount(key, minlength=n_keys)
-    ptr = torch.zeros(n_keys + 1, dtype=torch.int32, device=key.device)
-    ptr[1:] = torch.cumsum(counts, 0)
-    return ptr, order.to(torch.int32)
+def _csr(key, n_keys, want_perm=True):
+    """stable grouping of positions 0..len(key)-1 by key -> (ptr int32[n_keys+1], perm int32 or None), on the device:
+    esc_plan_csr (csrc/plan.hip: LSD radix passes of the positions + an integer histogram), no library sort.
+    Raises IndexError when a key lies outside [0, n_keys)."""
+    from . import _native as nv
+    if key.device.type != "cuda":
+        raise RuntimeError("esc_gnn_amd: execution plans are built on the GPU (got a %s tensor) - move the batch to the "
+                           "device first" % key.device.type)
+    key = key.contiguous()
+    if key.dtype != torch.int64:
+        key = key.to(torch.int64)
+    n, dev = key.numel(), key.device
+    ptr = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev) if want_perm else None
+    scratch = torch.empty(nv.lib().esc_plan_csr_scratch(n, n_keys), dtype=torch.int32, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    nv.call("esc_plan_csr", nv.ptr(key), n, n_keys, nv.ptr(ptr), nv.ptr(perm), nv.ptr(scratch), nv.ptr(bad), nv.stream())
+    if int(bad.item()):
+        raise IndexError("plan: a key lies outside [0, %d)" % n_keys)
+    return ptr, perm
 
 
 class BatchPlan(object):
@@ -56,16 +69,16 @@ class BatchPlan(object):
                   num_nodes=int(num_nodes), num_edges=int(E), nnz=0, n_cols=n_cols)
         if pos_batch is not None:
             Z = pos_batch.numel()
-            counts = torch.bincount(pos_batch, minlength=E)
-            if counts.numel() != E:
-                raise ValueError("pos_batch refers to edge %d but the batch has %d edges" % (counts.numel() - 1, E))
-            row_ptr = torch.zeros(E + 1, dtype=torch.int32, device=src.device)
-            row_ptr[1:] = torch.cumsum(counts, 0)
             if Z and not bool((pos_batch[1:] >= pos_batch[:-1]).all()):
                 raise ValueError("pos_batch must be non-decreasing (as create_subgraphs emits it)")
-            if Z and (int(pos_index.min()) < 0 or int(pos_index.max()) >= n_cols):
+            try:
+                row_ptr, _ = _csr(pos_batch, E, want_perm=False)        # already grouped by edge: pointers only
+            except IndexError:
+                raise ValueError("pos_batch refers to an edge beyond the batch's %d edges" % E)
+            try:
+                col_ptr, col_perm = _csr(pos_index, n_cols)
+            except IndexError:
                 raise IndexError("pos_index outside the %d-row z_initial table" % n_cols)
-            col_ptr, col_perm = _csr(pos_index, n_cols)
             cp = col_perm.long()
             kw.update(row_ptr=row_ptr, bag_idx=pos_index.to(torch.int32), bag_val=pos_enc.to(torch.int32),
                       col_ptr=col_ptr, col_row=pos_batch[cp].to(torch.int32),
@@ -73,13 +86,27 @@ class BatchPlan(object):
         return BatchPlan(**kw)
 
 
+def _sig(t):
+    return None if t is None else (t.data_ptr(), tuple(t.shape), t._version, str(t.device))
+
+
+def plan_key(data, n_cols=1800):
+    """identity of everything a plan was derived from: (address, shape, in-place version, device) of edge_index and the
+    bag tensors, the table height and the node count"""
+    return (_sig(data.edge_index), _sig(data["pos_enc"]), _sig(data["pos_index"]), _sig(data["pos_batch"]), n_cols,
+            data.num_nodes if data.x is None else data.x.size(0))
+
+
 def plan_of(data, n_cols=1800):
-    """Cached plan of a Data/Batch (built on first use, on the device the tensors live on)."""
+    """Cached plan of a Data/Batch (built on first use, on the device the tensors live on).  The cache is keyed on
+    plan_key(): assigning or editing edge_index / pos_* — edge dropout, augmentation, a re-used Batch object — rebuilds
+    the plan instead of aggregating over a stale one (which would read out-of-range int32 indices on the GPU)."""
     d = object.__getattribute__(data, "__dict__")
-    plan = d.get("_esc_plan")
-    ei = data.edge_index
-    if plan is None or plan.in_ptr.device != ei.device:
-        plan = BatchPlan.from_tensors(ei, data.num_nodes if data.x is None else data.x.size(0),
-                                      data["pos_enc"], data["pos_index"], data["pos_batch"], n_cols)
-        object.__setattr__(data, "_esc_plan", plan)
+    cached = d.get("_esc_plan")
+    key = plan_key(data, n_cols)
+    if cached is not None and getattr(cached, "_key", None) == key:
+        return cached
+    plan = BatchPlan.from_tensors(data.edge_index, key[5], data["pos_enc"], data["pos_index"], data["pos_batch"], n_cols)
+    plan._key = key
+    object.__setattr__(data, "_esc_plan", plan)
     return plan

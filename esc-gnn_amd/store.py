@@ -13,7 +13,7 @@ import torch
 
 from . import _native as nv
 from .batch import Batch
-from .plan import BatchPlan
+from .plan import BatchPlan, plan_key
 
 N_COLS = 1800
 
@@ -187,6 +187,7 @@ class DeviceGraphStore(object):
                          col_row=col_row, col_val=col_val, col_col=col_col, num_nodes=N, num_edges=E, nnz=Z,
                          n_cols=N_COLS)
         plan._keepalive = (slab, offs_d, ids_d)
+        plan._key = plan_key(out, N_COLS)                    # valid as long as nobody swaps or edits the index tensors
         object.__setattr__(out, "_esc_plan", plan)
         has_attr = self.edge_attr_all is not None
 

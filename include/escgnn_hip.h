@@ -98,6 +98,15 @@ typedef struct esc_sum_job { const float* v; int64_t n; float* out; } esc_sum_jo
 #define ESC_MAX_SUM_JOBS 16
 int esc_reduce_sum_jobs(const esc_sum_job* jobs, int count, void* stream);
 
+/* ---- execution plan of a foreign batch (plan.hip): stable grouping of positions by key = the CSR / CSC views ----------
+ * ptr[n_keys+1] = segment pointers, perm[n] = positions sorted by key, ties in ascending position (what a stable
+ * torch.sort + bincount + cumsum gave; reference call sites that these views serve: run_graphcount.py:155,161,169).
+ * perm may be NULL (keys already grouped: pointers only).  *bad_flag (device int) is set when a key is outside
+ * [0, n_keys).  scratch: esc_plan_csr_scratch(n, n_keys) int32. */
+int64_t esc_plan_csr_scratch(int64_t n, int64_t n_keys);
+int esc_plan_csr(const int64_t* key, int64_t n, int64_t n_keys, int32_t* ptr, int32_t* perm, int32_t* scratch,
+                 int32_t* bad_flag, void* stream);
+
 /* ---- a-7/a-8/a-9/a-10 dense layers on the matrix cores (exact-fp32 MFMA) -----------------
  * torch.nn.Linear call sites run_graphcount.py:54-121,183-189 (+ GINEConv.lin).
  * Y[M,N] = act(X)[M,K] * W[N,K]^T + bias[N]   (bias may be NULL)

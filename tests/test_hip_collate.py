@@ -8,6 +8,7 @@ import torch
 from conftest import load_collate, require_gpu
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 @pytest.fixture(scope="module")
@@ -81,3 +82,50 @@ def test_store_cache_round_trip(E, tmp_path):
     pa, pb = a.__dict__["_esc_plan"], b.__dict__["_esc_plan"]
     for f in E.BatchPlan.FIELDS:
         assert torch.equal(getattr(pa, f), getattr(pb, f)), f
+
+
+@pytest.mark.parametrize("n,n_keys,seed", [(0, 5, 0), (1, 1, 1), (63, 7, 2), (64, 300, 3), (2049, 255, 4), (15200, 2400, 5),
+                                          (550_000, 1800, 6), (70_001, 70_000, 7)])
+def test_plan_csr_kernel_is_a_stable_sort(E, n, n_keys, seed):
+    """esc_plan_csr (csrc/plan.hip: radix passes over the positions) against a stable torch.sort + bincount + cumsum on
+    the host: segment pointers and permutation bit-exact, for 1-, 2- and 3-pass key ranges, empty / one-element inputs,
+    chunk boundaries; out-of-range keys are reported."""
+    from esc_gnn_amd.plan import _csr
+    g = torch.Generator().manual_seed(seed)
+    key = torch.randint(0, n_keys, (n,), generator=g)
+    if n > 10:
+        key[: n // 3] = key[0]                     # a long run of one key: stability matters
+    ptr, perm = _csr(key.to(DEV), n_keys)
+    want_perm = torch.sort(key, stable=True)[1]
+    want_ptr = torch.zeros(n_keys + 1, dtype=torch.int64)
+    want_ptr[1:] = torch.cumsum(torch.bincount(key, minlength=n_keys), 0)
+    assert ptr.dtype == torch.int32 and perm.dtype == torch.int32
+    assert torch.equal(ptr.cpu().long(), want_ptr)
+    assert torch.equal(perm.cpu().long(), want_perm)
+    ptr2, none = _csr(key.to(DEV), n_keys, want_perm=False)
+    assert none is None and torch.equal(ptr2, ptr)
+    if n:
+        bad = key.clone(); bad[n // 2] = n_keys
+        with pytest.raises(IndexError):
+            _csr(bad.to(DEV), n_keys)
+
+
+def test_plan_cache_follows_the_index_tensors(E):
+    """plan_of() caches the CSR/CSC plan on the Data object; replacing or editing edge_index (edge dropout, augmentation,
+    a re-used Batch) must rebuild it instead of aggregating over the stale one."""
+    _, b, _ = load_collate("count3")
+    data = E.Data(**{k: torch.tensor(v) for k, v in b.items()}).to(DEV)
+    p1 = E.plan_of(data)
+    assert E.plan_of(data) is p1                                   # cached
+    keep = torch.arange(0, data.edge_index.size(1), 2, device=DEV)
+    data.edge_index = data.edge_index[:, keep]                      # assignment of a new tensor
+    sel = torch.isin(data.pos_batch, keep)
+    remap = torch.full((int(keep.max()) + 1,), -1, device=DEV, dtype=torch.long); remap[keep] = torch.arange(keep.numel(), device=DEV)
+    data.pos_enc, data.pos_index, data.pos_batch = data.pos_enc[sel], data.pos_index[sel], remap[data.pos_batch[sel]]
+    p2 = E.plan_of(data)
+    assert p2 is not p1 and p2.num_edges == keep.numel() and p2.nnz == int(sel.sum())
+    data.edge_index[0, 0] = data.edge_index[0, 1]                   # in-place edit: the version counter moves
+    p3 = E.plan_of(data)
+    assert p3 is not p2
+    src = data.edge_index[0][p3.out_edge.long()]
+    assert bool((src[1:] >= src[:-1]).all())

@@ -284,3 +284,62 @@ def test_ogb_variant_against_reference_golden():
         a = m(store.collate([0, 1, 2, 3]))
         c = m(E.Data(**{k: v.clone() for k, v in bt.items()}))
     assert torch.equal(a, c)
+
+
+def test_dense_edge_pos_branch_matches_sparse_bag_and_oracle():
+    """The reference's 'original, slow version' (run_graphcount.py:142-145): a dense int histogram `edge_pos` [E, 1800]
+    multiplied with z_initial.weight instead of the sparse (pos_enc, pos_index, pos_batch) bag.  Same predictions and
+    gradients as the oracle (which runs the sparse bag: the two are the same sum), training and eval mode."""
+    E, ref, mine, b = _setup(3, 16, "count3")
+    ref.train(); mine.train()
+    pr = ref(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
+    lr = torch.nn.functional.l1_loss(pr, b["y"].view(-1, 1))
+    lr.backward()
+    n_edges = b["edge_index"].shape[1]
+    dense = torch.zeros(n_edges, 1800, dtype=torch.int64)
+    dense.index_put_((b["pos_batch"], b["pos_index"]), b["pos_enc"], accumulate=True)
+    data = E.Data(x=b["x"].clone(), edge_index=b["edge_index"].clone(), y=b["y"].clone(), batch=b["batch"].clone(),
+                  edge_pos=dense)
+    assert "pos_enc" not in data and "edge_pos" in data
+    pm = mine(data)
+    lm = E.ops.l1_loss(pm, data.y)
+    lm.backward()
+    _close(pm, pr, "predictions (dense edge_pos)")
+    assert abs(float(lm.detach()) - float(lr.detach())) <= 1e-5 * max(1.0, abs(float(lr.detach())))
+    refp = dict(ref.named_parameters())
+    for n, p in mine.named_parameters():
+        _close_grad(n, p.grad, refp[n].grad)
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        er = ref(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
+        em = mine(E.Data(x=b["x"].clone(), edge_index=b["edge_index"].clone(), batch=b["batch"].clone(), edge_pos=dense))
+    _close(em, er, "eval predictions (dense edge_pos)")
+
+
+def test_eval_mode_with_gradients_runs_on_the_hip_kernels():
+    """model.eval() with autograd on (frozen BatchNorm statistics: fine-tuning, input-gradient probes): predictions and
+    every gradient against the oracle in eval mode — the BatchNorm layers use their running statistics and their
+    backward has no batch terms (ops._BnEvalAct on esc_bn_bwd_sums / esc_bn_bwd_apply)."""
+    E, ref, mine, b = _setup(3, 16, "count3", seed=3)
+    # give the running statistics a non-trivial value first: one training step on both sides
+    ref.train(); mine.train()
+    ref(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
+    mine(E.Data(**{k: v.clone() for k, v in b.items()}))
+    ref.eval(); mine.eval()
+    ref.zero_grad(); mine.zero_grad()
+    x_ref = b["x"].clone().requires_grad_(True)
+    pr = ref(x_ref, b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
+    torch.nn.functional.l1_loss(pr, b["y"].view(-1, 1)).backward()
+    data = E.Data(**{k: v.clone() for k, v in b.items()})
+    data.x = data.x.to("cuda:0").requires_grad_(True)
+    pm = mine(data)
+    E.ops.l1_loss(pm, data.y).backward()
+    _close(pm, pr, "eval-mode predictions")
+    _close(data.x.grad, x_ref.grad, "input gradient", tol=1e-5)
+    refp = dict(ref.named_parameters())
+    for n, p in mine.named_parameters():
+        assert p.grad is not None, n
+        _close(p.grad, refp[n].grad, "grad " + n, tol=1e-4)
+    for (n, v), (_, w) in zip(mine.named_buffers(), ref.named_buffers()):
+        if "num_batches" not in n:
+            _close(v, w, "buffer %s must not move in eval mode" % n, tol=1e-4 if n.startswith("x_embedding.") else 1e-5)
