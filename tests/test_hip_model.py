@@ -343,3 +343,41 @@ def test_eval_mode_with_gradients_runs_on_the_hip_kernels():
     for (n, v), (_, w) in zip(mine.named_buffers(), ref.named_buffers()):
         if "num_batches" not in n:
             _close(v, w, "buffer %s must not move in eval mode" % n, tol=1e-4 if n.startswith("x_embedding.") else 1e-5)
+
+
+@pytest.mark.parametrize("which", ["naive", "plus"])
+def test_gineplus_against_reference_class_golden(which):
+    """NAIVEGINEPLUS / GINEPLUS against outputs and gradients recorded from the reference's own class bodies
+    (/root/reference/modules/gine_operations.py:306-362, exec'd over a stand-in MessagePassing by
+    oracle/make_golden_gineplus.py): forward, d/dx of every list entry, d/d edge_attr, d/d eps and the inner MLP."""
+    require_gpu()
+    import esc_gnn_amd as E
+    from esc_gnn_amd.modules.gine_operations import GINEPLUS, NAIVEGINEPLUS
+    g = np.load(os.path.join(GOLDEN, "model_gineplus.npz"))
+    dev = "cuda:0"
+    k = int(g["k"])
+    dim = g[which + "_x0"].shape[1]
+    fun = torch.nn.Sequential(E.Linear(dim, dim), torch.nn.ReLU(), E.Linear(dim, dim))
+    conv = (NAIVEGINEPLUS if which == "naive" else GINEPLUS)(fun, dim, k=k).to(dev)
+    with torch.no_grad():
+        for n, p in conv.named_parameters():
+            p.copy_(torch.tensor(g["%s_param_%s" % (which, n)]))
+    mei, dist = torch.tensor(g["multihop_edge_index"]).to(dev), torch.tensor(g["distance"]).to(dev)
+    ea = torch.tensor(g[which + "_edge_attr"]).to(dev).requires_grad_(True)
+    nx = 1 if which == "naive" else k + 1
+    xs = [torch.tensor(g["%s_x%d" % (which, i)]).to(dev).requires_grad_(True) for i in range(nx)]
+    if which == "naive":
+        out = conv(xs[0], mei, dist, ea)
+    else:
+        ret = conv(list(xs), mei, dist, ea)
+        assert len(ret) == nx + 1 and all(a is b for a, b in zip(ret[1:], xs))
+        out = ret[0]
+    (out * torch.tensor(g[which + "_w"]).to(dev)).sum().backward()
+    _close(out, torch.tensor(g[which + "_out"]), which + " forward")
+    _close(ea.grad, torch.tensor(g[which + "_d_edge_attr"]), which + " d edge_attr")
+    for i, x in enumerate(xs):
+        want = torch.tensor(g["%s_dx%d" % (which, i)])
+        got = x.grad if x.grad is not None else torch.zeros_like(x)
+        _close(got, want, "%s dx%d" % (which, i))
+    for n, p in conv.named_parameters():
+        _close(p.grad, torch.tensor(g["%s_grad_%s" % (which, n)]), "%s grad %s" % (which, n), tol=2e-5)
