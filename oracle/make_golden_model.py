@@ -277,7 +277,10 @@ def main_ogb():
 
 
 if __name__ == "__main__":
-    main()
-    main_sr()
-    main_zinc()
-    main_ogb()
+    if "--only-ogb" in sys.argv:
+        main_ogb()
+    else:
+        main()
+        main_sr()
+        main_zinc()
+        main_ogb()
