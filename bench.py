@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--lr", type=float, default=1e-2)
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no_breakdown", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): --batch_size graphs per GPU and step; strong: ONE global batch of --batch_size graphs "
+                         "per step, sliced by graph over the ranks (SURVEY 8e)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="esc_tune_set(knob, value), repeatable")
     ap.add_argument("--streams", type=int, default=None,
                     help="esc_engine_set_side_stream mode (default: the library's; 0 = everything on one stream)")
@@ -91,7 +94,9 @@ def main():
     torch.manual_seed(0)
     # ---- dataset: synthetic graphs -> HIP feature build -> HBM-resident store -----------------------
     t0 = time.time()
-    first = rank * args.graphs                              # weak scaling: every rank owns its own split
+    # weak scaling: every rank owns its own split; strong scaling: every rank holds the SAME split and takes its slice of
+    # each global batch
+    first = 0 if args.scaling == "strong" else rank * args.graphs
     graphs = build_count_dataset(first, args.graphs, h=args.h, use_rd=True, self_loop=True)
     torch.cuda.synchronize()
     t_feat = time.time() - t0
@@ -107,7 +112,9 @@ def main():
     model = E.NestedGIN_eff(None, args.layers, args.hidden, use_rd=True, graph_pred=False, dropout=0,
                             edge_nest=True, use_cycle=True).to(dev)
     E.parallel.broadcast_parameters(model, 0)               # identical replicas
-    opt = E.optim.FlatAdam(model.parameters(), lr=args.lr)
+    # two gradient buckets (world > 1): the node pipeline's bucket is all-reduced while the edge pipeline's backward tail
+    # is still running, the edge pipeline's bucket (+ the node-count slot) after the join
+    opt = E.optim.FlatAdam(model.parameters(), lr=args.lr, late=E.parallel.edge_pipeline_parameters(model))
     model.train()
     engine = E.StepEngine(model) if args.path == "engine" else None
     if engine is None:
@@ -116,26 +123,38 @@ def main():
     stats = dict(graphs=0, nodes=0, edges=0, nnz=0)
 
     def tally(b):
-        stats["graphs"] += args.batch_size
+        stats["graphs"] += b.num_graphs
         stats["nodes"] += b.x.size(0)
         stats["edges"] += b.edge_index.size(1)
         stats["nnz"] += b.pos_enc.numel()
 
     nxt = {"b": None}
 
+    def next_ids(i):
+        """weak scaling: every rank walks its own split in batches of --batch_size graphs (per-GPU work fixed).
+        strong scaling: ONE global batch of --batch_size graphs per step, rank r collates its contiguous
+        slice [r*B/W, (r+1)*B/W) of it (run_graphcount.py's data-parallel mode)."""
+        ids = batch_ids[i % nb]
+        if args.scaling == "strong" and world > 1:
+            lo, hi = E.parallel.shard_slice(ids.numel(), rank, world)
+            return ids[lo:hi]
+        return ids
+
     def step(i, count=False):
         # host ids: async pinned staging, no host/device sync.  Engine path: the NEXT batch is collated between the two
         # halves of the step, i.e. on the node stream while the edge pipeline finishes its backward
-        b = nxt["b"] if nxt["b"] is not None else store.collate(batch_ids[i % nb])
+        b = nxt["b"] if nxt["b"] is not None else store.collate(next_ids(i))
         nxt["b"] = None
         if engine is not None:
             # world > 1: gradients of sum|err| (not the local mean): ONE RCCL all-reduce of grad ++ [n_local] gives the
             # global sums, and the division by the global node count rides on the Adam launch
             loss = engine.begin_step(b, loss_denom=1 if world > 1 else None)
-            nxt["b"] = store.collate(batch_ids[(i + 1) % nb])
+            nxt["b"] = store.collate(next_ids(i + 1))
+            if world > 1:
+                opt.all_reduce_early()                      # node-pipeline bucket: overlaps the edge tail
             engine.end_step()
             if world > 1:
-                opt.step(grad_denom=opt.all_reduce_sum(b.x.size(0)))
+                opt.step(grad_denom=opt.all_reduce_late(b.x.size(0)))
             else:
                 opt.step()
             if count:
@@ -251,12 +270,17 @@ def main():
     out = {
         "metric": "graphs/sec + edges-aggregated/sec, NestedGIN_eff h=3 bs=128 @1/2/4/8 GPU",
         "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "count_cycle-shaped random regular graphs (n in 10/15/20/30), target=triangles, "
                                "NestedGIN_eff h=%d layers=%d hidden=%d, bs=%d per GPU (configs[1])"
                                % (args.h, args.layers, args.hidden, args.batch_size),
-                   "global_batch": args.batch_size * world, "parallelism": "dp%d graph-sharded" % world, "step_path": args.path,
+                   "global_batch": args.batch_size * (world if args.scaling == "weak" else 1),
+                   "parallelism": "dp%d graph-sharded" % world, "step_path": args.path,
+                   "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                   "collective_backend": (dist.get_backend() if world > 1 else None),
+                   "grad_allreduce": ("two buckets: node-pipeline gradients during the edge backward tail, edge-pipeline gradients "
+                                      "+ node count after the join" if world > 1 else None),
                    "nodes_per_batch": round(N_avg, 1), "edges_per_batch": round(E_avg, 1),
                    "nnz_per_batch": round(stats["nnz"] / args.steps, 1)},
         "edges_aggregated_per_s": round(edges_agg_per_s, 1),

@@ -72,6 +72,10 @@ def default_appendix(appendix):
 def sharded_batches(store, batch_size, ctx, shuffle, generator=None):
     """Global batches of `batch_size` graphs in loader order; this rank collates its contiguous share."""
     G = len(store)
+    if shuffle and ctx.world > 1 and generator is None:
+        # the global CPU RNG would give every rank the same permutation only while all ranks consume it identically;
+        # any rank-dependent draw would silently shard DIFFERENT orders (graphs duplicated / dropped, no error anywhere)
+        raise ValueError("sharded_batches(shuffle=True) on %d ranks needs a dedicated, identically seeded torch.Generator" % ctx.world)
     order = torch.randperm(G, generator=generator) if shuffle else torch.arange(G)
     for i in range(0, G, batch_size):
         ids = order[i:i + batch_size]

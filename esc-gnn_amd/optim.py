@@ -10,11 +10,11 @@ from .parallel import FlatBucket
 
 
 class FlatAdam(FlatBucket):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, late=None):
         params = [p for p in params]
         if params and params[0].device.type != "cuda":
             raise RuntimeError("FlatAdam runs on the HIP device only; there is no CPU fallback")
-        super().__init__(params)
+        super().__init__(params, late=late)
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, params=self.params)]

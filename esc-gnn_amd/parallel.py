@@ -33,15 +33,28 @@ class FlatBucket(object):
                     # float4 paths apply to all of them (1-element tensors such as GINEConv.eps would otherwise
                     # push everything behind them off 16-byte alignment)
 
-    def __init__(self, params):
+    def __init__(self, params, late=None):
+        """late: parameters whose gradients are complete only at the very end of a step — for NestedGIN_eff the EDGE
+        pipeline's (z_initial, z_embedding.*, conv*.lin.*: their last contribution is the backward tail of the edge
+        stream, ~150 us after the node pipeline's gradients are final).  They are laid out BEHIND all other parameters,
+        so that the two groups are two contiguous buckets: `all_reduce_early` can run while the tail is still computing
+        (its collective overlaps it), `all_reduce_late` carries the rest plus the node-count slot."""
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("FlatBucket: no parameters")
+        late_ids = {id(p) for p in (late or [])}
+        if late_ids:
+            self.params = [p for p in self.params if id(p) not in late_ids] + [p for p in self.params if id(p) in late_ids]
         dev = self.params[0].device
         self.offsets, n = [], 0
+        self.early_numel = None
         for p in self.params:
+            if self.early_numel is None and id(p) in late_ids:
+                self.early_numel = n
             self.offsets.append(n)
             n += -(-p.numel() // self.ALIGN) * self.ALIGN
+        if self.early_numel is None:
+            self.early_numel = n
         self.numel = n
         self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)     # padding stays 0 (zero grad => no update)
         self._grad_store = torch.zeros(n + 1, dtype=torch.float32, device=dev)
@@ -78,6 +91,44 @@ class FlatBucket(object):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self._grad_store, op=dist.ReduceOp.SUM, group=group)
         return self._grad_store[-1:]
+
+
+    # ---- the same exchange in two buckets (sum-form gradients, StepEngine.begin_step / end_step) ------------------
+    def all_reduce_early(self, group=None):
+        """SUM all-reduce of the bucket of parameters that are NOT `late`: call between StepEngine.begin_step and
+        end_step — on the node stream the collective sits behind the node pipeline's gradient reductions and runs while
+        the edge pipeline finishes its backward tail."""
+        if self.early_numel and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self._grad_store[:self.early_numel], op=dist.ReduceOp.SUM, group=group)
+
+    def all_reduce_late(self, n_local, group=None):
+        """... and of the `late` bucket ++ [n_local] after end_step; returns the device scalar with the global count
+        (FlatAdam.step(grad_denom=...)).  early + late == all_reduce_sum, element for element."""
+        self._grad_store[-1:].fill_(float(n_local))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self._grad_store[self.early_numel:], op=dist.ReduceOp.SUM, group=group)
+        return self._grad_store[-1:]
+
+
+def edge_pipeline_parameters(model):
+    """The `late` set of a NestedGIN_eff-shaped model: parameters whose gradients come off the edge pipeline
+    (run_graphcount.py:54-61 z_embedding, :51 z_initial, GINEConv.lin)."""
+    out = []
+    for name, p in model.named_parameters():
+        head = name.split(".")[0]
+        if head in ("z_initial", "z_embedding") or ".lin." in ("." + name) and (head == "conv1" or head == "convs"):
+            out.append(p)
+    return out
+
+
+def broadcast_buffers(model, src=0, group=None):
+    """BatchNorm running statistics are updated from rank-local shards: before an evaluation or a checkpoint every rank
+    takes rank `src`'s (what DistributedDataParallel(broadcast_buffers=True) does), so that the logged validation number
+    is reproducible from the saved model."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in model.buffers():
+        dist.broadcast(t.data, src, group=group)
 
 
 def broadcast_parameters(model, src=0, group=None):

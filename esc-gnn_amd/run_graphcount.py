@@ -163,7 +163,7 @@ def main(argv=None):
     from . import ops
     from .engine import StepEngine
     from .optim import FlatAdam, ReduceLROnPlateau
-    from .parallel import broadcast_parameters, shard_slice
+    from .parallel import broadcast_buffers, broadcast_parameters, edge_pipeline_parameters, shard_slice
     from .store import DeviceGraphStore
 
     args = build_parser().parse_args(argv)
@@ -229,7 +229,9 @@ def main(argv=None):
         print("Using " + model.__class__.__name__ + " model")
     model = model.to(device)
     broadcast_parameters(model, 0)
-    optimizer = FlatAdam(model.parameters(), lr=args.lr)
+    # world > 1: two gradient buckets — node-pipeline parameters first, the edge pipeline's (whose gradients are final only
+    # after the backward tail) behind them
+    optimizer = FlatAdam(model.parameters(), lr=args.lr, late=edge_pipeline_parameters(model))
     scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=args.lr_decay_factor, patience=args.patience,
                                   min_lr=0.00001)
     engine = StepEngine(model)         # one native call per step; same parameters / .grad slots / BN buffers
@@ -265,10 +267,12 @@ def main(argv=None):
             loss = engine.begin_step(data, loss_denom=1 if world > 1 else None)
             ids = next(todo, None)
             upcoming = None if ids is None else stores[0].collate(ids)
+            if world > 1:
+                optimizer.all_reduce_early()        # overlaps the edge pipeline's backward tail
             engine.end_step()
             if world > 1:
                 loss_all += loss
-                optimizer.step(grad_denom=optimizer.all_reduce_sum(n_local))
+                optimizer.step(grad_denom=optimizer.all_reduce_late(n_local))
             else:
                 loss_all += loss * n_local
                 optimizer.step()
@@ -278,6 +282,9 @@ def main(argv=None):
         return float(loss_all) / n_train_targets
 
     def test(store):
+        # BatchNorm running statistics were updated from rank-local shards: evaluate (and later checkpoint) rank 0's on
+        # every rank, so that the logged MAE is the one the saved model reproduces
+        broadcast_buffers(model, 0)
         model.eval()
         err, num = torch.zeros((), device=device), 0
         with torch.no_grad():

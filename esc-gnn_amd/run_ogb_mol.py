@@ -93,7 +93,7 @@ def main(argv=None):
     from .harness import Context, default_appendix, open_result_dir, sharded_batches
     from .metrics import Evaluator
     from .optim import FlatAdam
-    from .parallel import broadcast_parameters
+    from .parallel import broadcast_buffers, broadcast_parameters
     from .store import DeviceGraphStore
 
     args = build_parser().parse_args(argv)
@@ -130,10 +130,10 @@ def main(argv=None):
     kwargs = dict(num_layer=args.num_layer, residual=args.residual, use_rd=args.use_rd, use_rp=args.use_rp,
                   adj_dropout=args.adj_dropout, subgraph_pooling=args.subgraph_pooling, graph_pooling=args.graph_pooling)
 
-    def train(model, optimizer):
+    def train(model, optimizer, gen):
         model.train()
         total = torch.zeros((), device=ctx.device)
-        for data, _ in sharded_batches(stores[0], args.batch_size, ctx, True):
+        for data, _ in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
             y = data.y.view(-1, num_tasks)
             optimizer.zero_grad()
             pred = model(data)
@@ -148,6 +148,7 @@ def main(argv=None):
 
     @torch.no_grad()
     def evaluate(model, store, checkpoints=(None,)):
+        broadcast_buffers(model, 0)                        # rank-local BatchNorm running statistics -> rank 0's everywhere
         model.eval()
         preds = []
         for ckpt in checkpoints:                           # checkpoint ensembling: mean of the predictions (:84-138)
@@ -175,6 +176,7 @@ def main(argv=None):
     start_run = args.run_from - 1
     for run in range(start_run, start_run + args.runs - args.run_from + 1):
         torch.manual_seed(run)                             # the reference leaves runs unseeded; seeded here for replay
+        gen = torch.Generator().manual_seed(run)           # the shuffle order every rank shards identically
         model = GNN(args.dataset, num_tasks, gnn_type="gin_eff", emb_dim=args.emb_dim, drop_ratio=args.drop_ratio,
                     virtual_node=args.virtual_node, RNI=args.RNI, deg_graph=None, deg_sub=None, **kwargs).to(ctx.device)
         broadcast_parameters(model, 0)
@@ -193,7 +195,7 @@ def main(argv=None):
         for epoch in range(start_epoch, start_epoch + epochs):
             ctx.say(f"=====Run {run + 1}, epoch {epoch}, {args.save_appendix}")
             ctx.say("Training...")
-            loss = train(model, optimizer)
+            loss = train(model, optimizer, gen)
             ctx.say("Evaluating...")
             valid_perf = evaluate(model, stores[1])[eval_metric]
             if valid_perf > best_valid_perf:

@@ -81,7 +81,7 @@ def main(argv=None):
 
     from .harness import Context, default_appendix, open_result_dir, seed_everything, sharded_batches
     from .optim import FlatAdam, ReduceLROnPlateau
-    from .parallel import broadcast_parameters
+    from .parallel import broadcast_buffers, broadcast_parameters
     from .store import DeviceGraphStore
 
     args = build_parser().parse_args(argv)
@@ -144,6 +144,7 @@ def main(argv=None):
         return float(ctx.all_reduce(loss_all)) / n_train
 
     def test(store):
+        broadcast_buffers(model, 0)                        # rank-local BatchNorm running statistics -> rank 0's everywhere
         model.eval()
         tot = torch.zeros(2, device=ctx.device)
         with torch.no_grad():

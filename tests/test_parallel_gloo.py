@@ -47,37 +47,57 @@ def _worker(rank, world, port, q, mode="weighted"):
             for p in m.parameters():
                 p.add_(1.0)
     E.parallel.broadcast_parameters(m, 0)
-    bucket = E.parallel.FlatBucket(m.parameters())
+    late = E.parallel.edge_pipeline_parameters(m) if mode == "two_bucket" else None
+    bucket = E.parallel.FlatBucket(m.parameters(), late=late)
     b = _shards(world)[rank]
     bucket.zero_grad()
     pred = m(b["x"], b["edge_index"], b["pos_enc"], b["pos_index"], b["pos_batch"], b["batch"])
     if mode == "weighted":                         # local-mean gradients, scaled around the collective
         torch.nn.functional.l1_loss(pred, b["y"].view(-1, 1)).backward()
         total = bucket.all_reduce_weighted(b["x"].size(0))
+    elif mode == "two_bucket":                     # the node pipeline's bucket first (overlaps the edge tail), then the rest
+        (pred - b["y"].view(-1, 1)).abs().sum().backward()
+        names = {id(p): n for n, p in m.named_parameters()}
+        k = [i for i, p in enumerate(bucket.params) if id(p) in {id(q) for q in late}]
+        assert k and k == list(range(k[0], len(bucket.params))), "late parameters must form the tail of the bucket"
+        assert all(names[id(p)].split(".")[0] in ("z_initial", "z_embedding") or ".lin." in names[id(p)] for p in late)
+        assert 0 < bucket.early_numel < bucket.numel and bucket.early_numel == bucket.offsets[k[0]]
+        before = bucket.flat_grad[bucket.early_numel:].clone()
+        bucket.all_reduce_early()
+        assert torch.equal(bucket.flat_grad[bucket.early_numel:], before)      # the late bucket has not moved yet
+        total = bucket.all_reduce_late(b["x"].size(0))
+        bucket.flat_grad.div_(total)
     else:                                          # sum-gradients; the division belongs to the optimiser launch
         (pred - b["y"].view(-1, 1)).abs().sum().backward()
         total = bucket.all_reduce_sum(b["x"].size(0))
         bucket.flat_grad.div_(total)               # what esc_adam_step_scaled does per element
     # parameters / gradients are views into the (64-byte aligned, padded) flat buffers: compare them unpadded
-    grads = torch.cat([p.grad.reshape(-1) for p in bucket.params])
-    params = torch.cat([p.data.reshape(-1) for p in bucket.params])
+    # (in model order, whatever the bucket layout)
+    grads = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    params = torch.cat([p.data.reshape(-1) for p in m.parameters()])
     assert all(p.grad.data_ptr() == bucket.flat_grad[o:].data_ptr() and o % bucket.ALIGN == 0
                for p, o in zip(bucket.params, bucket.offsets))
-    q.put((rank, grads.detach().numpy().copy(), float(total), params.detach().numpy().copy()))
+    # BatchNorm buffers drift apart under per-shard statistics; broadcast_buffers re-aligns them before eval / checkpoints
+    bufs_before = torch.cat([v.reshape(-1).float() for v in m.buffers()])
+    E.parallel.broadcast_buffers(m, 0)
+    bufs_after = torch.cat([v.reshape(-1).float() for v in m.buffers()])
+    q.put((rank, grads.detach().numpy().copy(), float(total), params.detach().numpy().copy(),
+           bufs_before.numpy().copy(), bufs_after.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["weighted", "sum"])
+@pytest.mark.parametrize("mode", ["weighted", "sum", "two_bucket"])
 def test_two_rank_gradient_equals_sharded_objective(mode):
-    world, port = 2, 29000 + (os.getpid() + (7 if mode == "sum" else 0)) % 2000
+    world, port = 2, 29000 + (os.getpid() + {"weighted": 0, "sum": 7, "two_bucket": 13}[mode]) % 2000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
-    res = [(r, torch.from_numpy(g), t, torch.from_numpy(p)) for r, g, t, p in res]
+    bufs = [(torch.from_numpy(x[4]), torch.from_numpy(x[5])) for x in res]
+    res = [(x[0], torch.from_numpy(x[1]), x[2], torch.from_numpy(x[3])) for x in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -98,6 +118,8 @@ def test_two_rank_gradient_equals_sharded_objective(mode):
         err = float((grad - want).abs().max()) / max(1.0, float(want.abs().max()))
         assert err < 1e-5, (rank, err)
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])
+    assert not torch.equal(bufs[0][0], bufs[1][0])           # per-shard running statistics differ ...
+    assert torch.equal(bufs[0][1], bufs[1][1]) and torch.equal(bufs[0][1], bufs[0][0])   # ... until rank 0's are broadcast
 
 
 def test_shard_slice_covers_batch():
