@@ -62,6 +62,10 @@ SIGNATURES = {
     "esc_linear_stats_block_rows": [P, I64, P, I64, I64, I64, I64],
     "esc_linear_fold_available": [],
     "esc_engine_phase_times": [POINTER(c_double), I32],
+    "esc_engine_set_collective": [P, P, I32, I32, P, P, I64],
+    "esc_bn_sync_pack": [P, P, I64, F32, I64, I32, I32, P, P],
+    "esc_bn_sync_finalize": [P, I32, I64, F32, F32, P, P, P, P, P, P, P, P, P, P],
+    "esc_bn_sync_coef": [P, I64, P, P],
     "esc_linear_fwd_fold": [P, I64, P, I64, P, POINTER(BnFold), I64, I64, I64, P, I64, P, P],
     "esc_bn_stats_from_partials_rows": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P],
     "esc_affine_act_fold": [P, I64, I64, I64, POINTER(BnFold), I32, P, I64, P],

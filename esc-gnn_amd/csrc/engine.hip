@@ -29,7 +29,7 @@ struct Arena {
   }
 };
 
-struct BnWs { float *mean, *invstd, *scale, *shift; };
+struct BnWs { float *mean, *invstd, *scale, *shift, *nglob; };     // nglob: rows over all ranks (SyncBN)
 struct MlpWs { float *Y0, *Y1; BnWs b0, b1; };
 
 struct Layout {
@@ -51,7 +51,7 @@ struct Layout {
   int64_t total;
 };
 
-static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); return w; }
+static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); w.nglob = a.take(16); return w; }
 
 static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z, float* base, bool train) {
   Layout y{};
@@ -256,32 +256,86 @@ static esc_bn_fold make_fold(const float* partials, int64_t rows, int64_t block_
                      bn.running_mean, bn.running_var};
 }
 
+// ---- SyncBN (esc_engine_set_collective): statistics over all ranks of a graph-sharded step ----------------------------
+struct Collective {
+  esc_allreduce_fn fn = nullptr; void* user = nullptr;
+  int rank = 0, world = 1;
+  float *buf_node = nullptr, *buf_edge = nullptr; int64_t cap = 0;
+};
+static Collective g_coll;
+static bool sync_on(const Ctx& c) { return c.train && g_coll.fn != nullptr && g_coll.world > 1; }
+static float* sync_buf(const Ctx& c) {
+  EdgeStream& es = edge_stream();
+  return (es.ok && c.s == (void*)es.stream) ? g_coll.buf_edge : g_coll.buf_node;
+}
+static int sync_allreduce(const Ctx& c, float* buf, int64_t n) {
+  ESC_REQUIRE(buf != nullptr && n <= g_coll.cap, "esc_engine: SyncBN exchange buffer too small (%ld > %ld floats)", (long)n, (long)g_coll.cap);
+  const int rc = g_coll.fn(buf, n, c.s, g_coll.user);
+  if (rc != 0) { set_error("esc_engine: the collective provider failed (%d)", rc); return ESC_ELAUNCH; }
+  return ESC_OK;
+}
+// w.mean / w.invstd hold THIS rank's statistics over its M rows: replace them (and the consumer-side coefficients, the
+// running statistics) by the statistics over all ranks' rows
+static int bn_sync_forward(const Ctx& c, int64_t M, const esc_bn_t& bn, const BnWs& w) {
+  const int64_t C = c.y.H;
+  float* buf = sync_buf(c);
+  ESC_TRY(esc_bn_sync_pack(w.mean, w.invstd, M, bn.eps, C, g_coll.rank, g_coll.world, buf, c.s));
+  ESC_TRY(sync_allreduce(c, buf, (int64_t)g_coll.world * 3 * C));
+  return esc_bn_sync_finalize(buf, g_coll.world, C, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var,
+                              bn.gamma, bn.beta, w.scale, w.shift, w.nglob, c.s);
+}
+// BatchNorm(+ReLU) backward; d(gamma), d(beta) stay this rank's sums (the gradient all-reduce adds them up)
+static int bn_backward(const Ctx& c, const float* X, int64_t ldx, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
+                       int64_t M, const BnWs& w, const esc_bn_t& bn, float* dX, int64_t lddx, float* scratch) {
+  const int64_t C = c.y.H;
+  if (!sync_on(c))
+    return esc_bn_bwd(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, 1, dX, lddx, bn.dgamma, bn.dbeta,
+                      scratch, c.s);
+  float* buf = sync_buf(c);
+  ESC_TRY(esc_bn_bwd_sums(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, 1, buf, bn.dgamma, bn.dbeta,
+                          scratch, c.s));
+  ESC_TRY(sync_allreduce(c, buf, 2 * C));
+  ESC_TRY(esc_bn_sync_coef(buf, C, w.nglob, c.s));
+  return esc_bn_bwd_apply(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, 1, buf, dX, lddx, c.s);
+}
+
 // Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
 static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linear_t& lin, const float* sc, const float* sh,
                      int64_t M, float* Y, const esc_bn_t& bn, const BnWs& w) {
   const LdsFloorGuard cap(c.on_edge_stream && g_cap_forward);
   const int64_t H = c.y.H, K = lin.in_dim;
+  const bool sync = sync_on(c);     // statistics over all ranks: local ones first (no running update, no coefficients), then the exchange
   const bool fused = c.train && g_gemm_stats && H > 32 && c.jobs != nullptr;   // main chain only (col_stats is shared scratch)
-  if (fused && g_fuse_finalize && M > 1) {    // statistics AND their merge ride on the GEMM launch
+  if (fused && g_fuse_finalize && M > 1 && !sync) {    // statistics AND their merge ride on the GEMM launch
     esc_bn_fuse f{bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma, bn.beta, w.scale, w.shift};
     return esc_linear_bn_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, c.y.col_stats, &f, c.s);
   }
   ESC_TRY(esc_linear_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, fused ? c.y.col_stats : nullptr, c.s));
-  if (fused)
-    return esc_bn_stats_from_partials_rows(c.y.col_stats, M, H, esc_linear_stats_block_rows(X, ld_x, lin.w, K, M, H, K), bn.eps,
-                                           bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma, bn.beta,
-                                           w.scale, w.shift, c.s);
-  if (c.train)
-    return esc_bn_stats(Y, H, M, H, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma,
-                        bn.beta, w.scale, w.shift, c.y.bn_scratch, c.s);
+  if (fused) {
+    ESC_TRY(esc_bn_stats_from_partials_rows(c.y.col_stats, M, H, esc_linear_stats_block_rows(X, ld_x, lin.w, K, M, H, K), bn.eps,
+                                            bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
+                                            sync ? nullptr : bn.running_var, bn.gamma, bn.beta, sync ? nullptr : w.scale,
+                                            sync ? nullptr : w.shift, c.s));
+    return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
+  }
+  if (c.train) {
+    ESC_TRY(esc_bn_stats(Y, H, M, H, bn.eps, bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
+                         sync ? nullptr : bn.running_var, bn.gamma, bn.beta, sync ? nullptr : w.scale, sync ? nullptr : w.shift,
+                         c.y.bn_scratch, c.s));
+    return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
+  }
   return esc_bn_eval_coef(bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, H, w.scale, w.shift, c.s);
 }
 
 static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const esc_bn_t& bn, const BnWs& w) {
   const int64_t C = c.y.H;
-  if (c.train)
-    return esc_bn_stats(X, ld, M, C, bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var,
-                        bn.gamma, bn.beta, w.scale, w.shift, c.y.bn_scratch, c.s);
+  if (c.train) {
+    const bool sync = sync_on(c);
+    ESC_TRY(esc_bn_stats(X, ld, M, C, bn.eps, bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
+                         sync ? nullptr : bn.running_var, bn.gamma, bn.beta, sync ? nullptr : w.scale, sync ? nullptr : w.shift,
+                         c.y.bn_scratch, c.s));
+    return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
+  }
   return esc_bn_eval_coef(bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, C, w.scale, w.shift, c.s);
 }
 
@@ -289,7 +343,7 @@ static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const 
 // node-sized training-mode MLPs: no finalize launches — each BatchNorm's partials are merged by its consumer
 static bool fold_ok(const Ctx& c, int64_t M) {
   const int64_t H = c.y.H;
-  return c.train && g_fold && g_gemm_stats && esc_linear_fold_available() && c.jobs != nullptr && !c.on_edge_stream && M > 1 && M <= 4096 && H % 32 == 0 &&
+  return c.train && g_fold && !sync_on(c) && g_gemm_stats && esc_linear_fold_available() && c.jobs != nullptr && !c.on_edge_stream && M > 1 && M <= 4096 && H % 32 == 0 &&
          H > 32 && H <= 1024;
 }
 
@@ -315,11 +369,9 @@ static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const 
                         int64_t ld_da) {
   const Layout& y = c.y;
   const int64_t H = y.H;
-  ESC_TRY(esc_bn_bwd(w.Y1, H, out, ld_out, dOut, ld_dout, M, H, w.b1.mean, w.b1.invstd, p.bn1.gamma, p.bn1.beta, 1,
-                     y.dT1, H, p.bn1.dgamma, p.bn1.dbeta, y.bn_scratch, c.s));
+  ESC_TRY(bn_backward(c, w.Y1, H, out, ld_out, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));
   ESC_TRY(linear_backward(c, y.dT1, H, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1, M, y.dT2, H, 0));
-  ESC_TRY(esc_bn_bwd(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, 1,
-                     y.dT2, H, p.bn0.dgamma, p.bn0.dbeta, y.bn_scratch, c.s));
+  ESC_TRY(bn_backward(c, w.Y0, H, nullptr, 0, y.dT2, H, M, w.b0, p.bn0, y.dT2, H, y.bn_scratch));
   return linear_backward(c, y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0);
 }
 
@@ -439,8 +491,7 @@ static int backward(const Ctx& c, Pending* defer) {
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W;
   // lin2 <- dpred
   ESC_TRY(linear_backward(c, y.dpred, 1, y.Yl, H, y.bl.scale, y.bl.shift, m->lin2, N, y.dAl, H, 0));
-  ESC_TRY(esc_bn_bwd(y.Yl, H, nullptr, 0, y.dAl, H, N, H, y.bl.mean, y.bl.invstd, m->bn_lin1.gamma, m->bn_lin1.beta, 1,
-                     y.dAl, H, m->bn_lin1.dgamma, m->bn_lin1.dbeta, y.bn_scratch, c.s));
+  ESC_TRY(bn_backward(c, y.Yl, H, nullptr, 0, y.dAl, H, N, y.bl, m->bn_lin1, y.dAl, H, y.bn_scratch));
   // lin1 backward.  The node chain needs d(cat)[:, L*H:] (the last layer's output gradient) at once and the other
   // slices only when the first aggregate backward accumulates into them ~60 us later: with an edge stream the last
   // column block (dX slice + its dW columns) is computed here and the other L blocks over there, concurrently.
@@ -514,14 +565,12 @@ static int backward(const Ctx& c, Pending* defer) {
   // x_embedding backward queued above on the node stream
   const bool mat = g_materialise_edge_act != 0;
   // (the ReLU mask is recomputed from the pre-BN value even when the activation was materialised: one array less to read)
-  ESC_TRY(esc_bn_bwd(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma,
-                     m->zbn1.beta, 1, y.dZemb, H, m->zbn1.dgamma, m->zbn1.dbeta, ce.y.bn_scratch, ce.s));
+  ESC_TRY(bn_backward(ce, y.Yz, H, nullptr, 0, y.dZemb, H, E, y.zb1, m->zbn1, y.dZemb, H, ce.y.bn_scratch));
   Ctx ct = ce;
   ct.on_edge_stream = ce.on_edge_stream && g_cap_tail;    // the tail is the critical path: its GEMM runs at full occupancy
   if (mat) ESC_TRY(linear_backward(ct, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
   else     ESC_TRY(linear_backward(ct, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
-  ESC_TRY(esc_bn_bwd(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1,
-                     y.dAz, H, m->zbn0.dgamma, m->zbn0.dbeta, ce.y.bn_scratch, ce.s));
+  ESC_TRY(bn_backward(ce, y.Zb, H, nullptr, 0, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, ce.y.bn_scratch));
   ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E,
                                  1, m->dz_table, y.bag_scratch, ce.s));
   mark(PH_NODE_BWD_DONE, c.s);
@@ -598,6 +647,14 @@ int esc_engine_phase_times(double* out, int skip) {
   }
   for (int i = 0; i < 6; ++i) out[i] /= n > 0 ? n : 1;
   return n;
+}
+
+int esc_engine_set_collective(esc_allreduce_fn fn, void* user, int rank, int world, float* buf_node, float* buf_edge,
+                              int64_t cap) {
+  ESC_REQUIRE(fn == nullptr || (world >= 1 && rank >= 0 && rank < world && buf_node && buf_edge && cap > 0),
+              "esc_engine_set_collective: bad argument");
+  g_coll = Collective{fn, user, rank, world < 1 ? 1 : world, buf_node, buf_edge, cap};
+  return ESC_OK;
 }
 
 int esc_engine_set_gemm_stats(int on) {

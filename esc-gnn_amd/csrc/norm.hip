@@ -501,6 +501,61 @@ __global__ __launch_bounds__(256) void bn_eval_coef_kernel(const float* __restri
   shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
 }
 
+// ---- SyncBN inside the step engine (graph-sharded data parallelism) -----------------------------------------
+// Every rank packs its (count, mean, M2) per channel into ITS slot of a zeroed [world][3][C] buffer; one SUM all-reduce
+// is then an all-gather; the slots are Chan-merged in rank order (fp64) on every rank: identical global statistics.
+__global__ __launch_bounds__(256) void bn_sync_pack_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float n_local, float eps, int C, int rank, int world,
+                                                           float* __restrict__ buf) {
+  ESC_PRIO();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = invstd[c];
+  const float m2 = n_local * fmaxf(1.f / (is * is) - eps, 0.f);        // biased variance * n
+  for (int r = 0; r < world; ++r) {
+    float* b = buf + (size_t)r * 3 * C;
+    const bool me = r == rank;
+    b[c] = me ? n_local : 0.f;
+    b[C + c] = me ? mean[c] : 0.f;
+    b[2 * C + c] = me ? m2 : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void bn_sync_finalize_kernel(const float* __restrict__ buf, int world, int C, float eps,
+                                                               float momentum, float* __restrict__ mean,
+                                                               float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float* __restrict__ n_total) {
+  ESC_PRIO();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const float* b = buf + (size_t)r * 3 * C;
+    chan_merge(n, mu, m2, (double)b[c], (double)b[C + c], (double)b[2 * C + c]);
+  }
+  const float is = (float)(1.0 / sqrt(m2 / n + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  if (scale) {
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - (float)mu * sc;
+  }
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (n - 1.0));
+  if (c == 0 && n_total) *n_total = (float)n;
+}
+// backward: the all-reduced column sums (sum g, sum g*xhat) become the means over ALL ranks' rows
+__global__ __launch_bounds__(256) void bn_sync_coef_kernel(float2* __restrict__ coef, int C, const float* __restrict__ n_total) {
+  ESC_PRIO();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv = 1.f / *n_total;
+  const float2 v = coef[c];
+  coef[c] = make_float2(v.x * inv, v.y * inv);
+}
+
 // >= 4 rows per wave slot (scalar kernels keep the old 64-block cap: their finalize cost grows with the slot count)
 // forward statistics: 64 (their finalize merges 4 slots per block with Chan's formula, its cost grows with the count);
 // backward sums: norm_rowblock_cap() = 256 (one slot per block, plain sums) — swept on MI355X: 35 -> 28 us edge-sized
@@ -614,6 +669,34 @@ int esc_affine_act(const float* X, int64_t ld_x, int64_t M, int64_t C, const flo
   else if (vec) esc::launch(ESC_K_NORM, affine_act_kernel<4>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
   else          esc::launch(ESC_K_NORM, affine_act_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ld_x, M, (int)C, scale, shift, relu, Y, ld_y);
   ESC_CHECK_LAUNCH("esc_affine_act");
+  return ESC_OK;
+}
+
+int esc_bn_sync_pack(const float* mean, const float* invstd, int64_t n_local, float eps, int64_t C, int rank, int world,
+                     float* buf, void* stream) {
+  ESC_REQUIRE(mean && invstd && buf && C > 0 && world > 0 && rank >= 0 && rank < world && n_local > 0, "esc_bn_sync_pack: bad argument");
+  esc::launch(ESC_K_NORM, bn_sync_pack_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, invstd,
+              (float)n_local, eps, (int)C, rank, world, buf);
+  ESC_CHECK_LAUNCH("esc_bn_sync_pack");
+  return ESC_OK;
+}
+
+int esc_bn_sync_finalize(const float* buf, int world, int64_t C, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, const float* gamma, const float* beta, float* scale,
+                         float* shift, float* n_total, void* stream) {
+  ESC_REQUIRE(buf && mean && invstd && C > 0 && world > 0, "esc_bn_sync_finalize: bad argument");
+  ESC_REQUIRE((scale == nullptr) == (shift == nullptr), "esc_bn_sync_finalize: scale/shift must come together");
+  esc::launch(ESC_K_NORM, bn_sync_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, buf, world,
+              (int)C, eps, momentum, mean, invstd, running_mean, running_var, gamma, beta, scale, shift, n_total);
+  ESC_CHECK_LAUNCH("esc_bn_sync_finalize");
+  return ESC_OK;
+}
+
+int esc_bn_sync_coef(float* coef, int64_t C, const float* n_total, void* stream) {
+  ESC_REQUIRE(coef && n_total && C > 0, "esc_bn_sync_coef: bad argument");
+  esc::launch(ESC_K_NORM, bn_sync_coef_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+              reinterpret_cast<float2*>(coef), (int)C, n_total);
+  ESC_CHECK_LAUNCH("esc_bn_sync_coef");
   return ESC_OK;
 }
 

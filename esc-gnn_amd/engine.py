@@ -97,14 +97,59 @@ def describe(m, gp=_grad_ptr):
     return d
 
 
+def _sync_groups(m):
+    return [mod.sync_group for mod in m.modules() if getattr(mod, "sync_group", False) is not False]
+
+
 def engine_supports(m):
-    """The configuration the whole-step engine covers: the run_graphcount one (reference :465)."""
+    """The configuration the whole-step engine covers: the run_graphcount one (reference :465).  BatchNorm statistics over
+    several ranks (nn.BatchNorm1d.convert_sync) are served too: the engine exchanges them through a collective provider
+    (install_collective below) — all BatchNorms of the model must then use the same process group."""
     if m.graph_pred or m.dropout != 0 or not m.use_cycle or m.lin1.weight.device.type != "cuda":
         return False
     if m.lin2.out_features != 1 or m.lin2.in_features % 4 != 0:
         return False
-    # BatchNorm statistics over several ranks (SyncBN) need collectives between the layers: per-op path only
-    return all(getattr(mod, "sync_group", False) is False for mod in m.modules())
+    groups = _sync_groups(m)
+    n_bn = sum(1 for mod in m.modules() if hasattr(mod, "sync_group"))
+    return not groups or (len(groups) == n_bn and all(g is groups[0] for g in groups))
+
+
+_ALLREDUCE_T = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_int64, c_void_p, c_void_p)
+_collective = {}            # the installed provider: keeps the callback object, the exchange buffers and the group alive
+
+
+def install_collective(hidden, device, group=None):
+    """Give the step engine its all-reduce (SyncBN under graph-sharded data parallelism): RCCL through
+    torch.distributed (backend "nccl" on MI355X; gloo in the two-rank tests).  The engine calls back with one of the two
+    exchange buffers allocated here and the HIP stream the exchange must be ordered on."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        nv.call("esc_engine_set_collective", None, None, 0, 1, None, None, 0)
+        _collective.clear()
+        return False
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    cap = world * 3 * hidden
+    bufs = [torch.zeros(cap, dtype=torch.float32, device=device) for _ in range(2)]
+    by_ptr = {b.data_ptr(): b for b in bufs}
+
+    def allreduce(buf, n, stream, user):
+        try:
+            t = by_ptr[buf][:n]
+            cur = torch.cuda.current_stream(device)
+            if stream is None or stream == cur.cuda_stream:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:                                         # the edge pipeline's own stream
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=device)):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as exc:                          # never let an exception cross the C boundary
+            print("esc_gnn_amd: collective provider failed: %r" % (exc,))
+            return 1
+
+    cb = _ALLREDUCE_T(allreduce)
+    nv.call("esc_engine_set_collective", ctypes.cast(cb, c_void_p), None, rank, world, bufs[0].data_ptr(), bufs[1].data_ptr(), cap)
+    _collective.update(cb=cb, bufs=bufs, group=group, world=world)
+    return True
 
 
 class StepEngine(object):
@@ -116,6 +161,11 @@ class StepEngine(object):
             raise RuntimeError("StepEngine runs on the HIP device only; there is no CPU fallback")
         self.model = model
         self._ws = None
+        groups = _sync_groups(model)
+        if groups:                                           # SyncBN: the engine exchanges the statistics itself
+            if not engine_supports(model):
+                raise NotImplementedError("StepEngine: all BatchNorm layers must share one sync group")
+            install_collective(model.lin2.in_features, model.lin1.weight.device, groups[0])
         self._bn_counters = [m.num_batches_tracked for m in model.modules()
                              if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
         self.refresh()
@@ -202,7 +252,8 @@ class _NodeCache(object):
     def __init__(self, model):
         import numpy as np
         self.params = list(model.parameters())
-        self.key = tuple(p.data_ptr() for p in self.params)
+        self.buffers = [b for b in model.buffers() if b.is_floating_point()]   # the template bakes the running-stat addresses in
+        self.key = tuple(t.data_ptr() for t in self.params + self.buffers)
         self.counters = [m.num_batches_tracked for m in model.modules()
                          if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
         index = {id(p): i for i, p in enumerate(self.params)}
@@ -219,7 +270,7 @@ class _NodeCache(object):
         self.byte_offsets = np.asarray(offs, dtype=np.uint64)[self.slot_param] * np.uint64(4)
 
     def valid(self):
-        return self.key == tuple(p.data_ptr() for p in self.params)
+        return self.key == tuple(t.data_ptr() for t in self.params + self.buffers)
 
     def descriptor(self, grad_base):
         import numpy as np
@@ -272,5 +323,8 @@ class _EngineNode(torch.autograd.Function):
 
 
 def engine_forward(model, data):
+    groups = _sync_groups(model)
+    if groups and _collective.get("group", False) is not groups[0]:      # SyncBN: the engine needs its all-reduce
+        install_collective(model.lin2.in_features, model.lin1.weight.device, groups[0])
     cache = _node_cache(model)
     return _EngineNode.apply(model, data, cache, *cache.params)

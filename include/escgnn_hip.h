@@ -325,6 +325,22 @@ int esc_engine_set_materialise_edge_act(int on);
 /* 1 (default): BatchNorm statistics come from the producing GEMM's epilogue (col_stats) and are merged by that
  * launch's last workgroups (esc_linear_bn_fwd); 3: same epilogue, separate finalize launch; 0: a pass over Y */
 int esc_engine_set_gemm_stats(int on);
+/* ---- SyncBN inside the step engine: BatchNorm statistics over ALL ranks of a graph-sharded step ----------
+ * The library links no communication stack: the host hands the engine ONE function that sums a device buffer over the
+ * ranks, in place, ordered on the given HIP stream (RCCL via torch.distributed in esc_gnn_amd/engine.py; gloo in the
+ * two-rank tests).  buf_node / buf_edge are the caller-owned exchange buffers of the two pipelines (cap floats each,
+ * >= world * 3 * hidden).  Per BatchNorm: forward = local statistics -> esc_bn_sync_pack -> all-reduce (an all-gather of
+ * (count, mean, M2) slots) -> esc_bn_sync_finalize (Chan merge in rank order); backward = esc_bn_bwd_sums -> all-reduce
+ * of 2C sums -> esc_bn_sync_coef -> esc_bn_bwd_apply.  fn == NULL or world <= 1 switches it off. */
+typedef int (*esc_allreduce_fn)(float* buf, int64_t n, void* stream, void* user);
+int esc_engine_set_collective(esc_allreduce_fn fn, void* user, int rank, int world, float* buf_node, float* buf_edge,
+                              int64_t cap);
+int esc_bn_sync_pack(const float* mean, const float* invstd, int64_t n_local, float eps, int64_t C, int rank, int world,
+                     float* buf, void* stream);
+int esc_bn_sync_finalize(const float* buf, int world, int64_t C, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, const float* gamma, const float* beta, float* scale,
+                         float* shift, float* n_total, void* stream);
+int esc_bn_sync_coef(float* coef, int64_t C, const float* n_total, void* stream);
 /* diagnostics (ESC_PHASE_TIMING=1 in the environment): mean ms between event marks of the two pipelines over the recorded
  * steps; call after a device synchronise.  Returns the number of steps averaged. */
 int esc_engine_phase_times(double* out6, int skip_first);

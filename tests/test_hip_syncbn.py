@@ -29,7 +29,7 @@ def _setup():
     return E, store, model
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, path="autograd"):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,9 +40,21 @@ def _worker(rank, world, port, q):
     lo, hi = E.parallel.shard_slice(12, rank, world)
     b = store.collate(ids[lo:hi])
     n_glob = int(store.h_node_ptr[12])
-    pred = model(b)
-    loss = E.ops.l1_loss(pred, b.y, denom=n_glob)            # this rank's share of the global mean
-    loss.backward()
+    if path == "engine":                                     # the whole-step engine exchanges the statistics itself
+        assert E.engine.engine_supports(model)
+        eng = E.StepEngine(model)
+        loss, pred = eng.train_step(b, loss_denom=n_glob, return_pred=True)
+    elif path == "engine_node":                              # model(batch) as ONE autograd node on the engine
+        model.engine_forward = True
+        pred = model(b)
+        assert type(pred.grad_fn).__name__.startswith("_EngineNode")
+        loss = E.ops.l1_loss(pred, b.y, denom=n_glob)
+        loss.backward()
+    else:
+        model.engine_forward = False
+        pred = model(b)
+        loss = E.ops.l1_loss(pred, b.y, denom=n_glob)            # this rank's share of the global mean
+        loss.backward()
     grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     dist.all_reduce(grads)
     tot = loss.detach().clone()
@@ -53,12 +65,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_syncbn_equals_full_batch():
+@pytest.mark.parametrize("path", ["autograd", "engine", "engine_node"])
+def test_two_rank_syncbn_equals_full_batch(path):
+    """per-op autograd path (ops.sync_batch_norm_act), the whole-step engine (esc_engine_set_collective: 13 forward + 13
+    backward exchanges per step issued from C++ through the provider) and the engine as an autograd node."""
     require_gpu()
-    world, port = 2, 29600 + os.getpid() % 300
+    world, port = 2, 29600 + (os.getpid() + {"autograd": 0, "engine": 11, "engine_node": 23}[path]) % 300
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, path)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
