@@ -104,9 +104,9 @@ SIGNATURES = {
     "esc_adam_step_scaled": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P, P],
     "esc_collate_cols": [P, I64, P, I64, P, P, P, P],
     "esc_collate_fill": [POINTER(CollateArgs), P],
-    "esc_features_scratch_bytes": [I64, I64, I64],
-    "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
-    "esc_features_fill": [P, P, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
+    "esc_features_scratch_bytes": [I64, I64, I64, I64, I64, I32],
+    "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
+    "esc_features_fill": [P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
 _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_prof_read_all": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,

@@ -35,7 +35,7 @@ def encode_edge_lists(node_counts, edge_lists, h, use_rd, self_loop):
     edge_ptr = torch.zeros(G + 1, dtype=torch.int64)
     node_ptr[1:] = torch.cumsum(n_t, 0)
     edge_ptr[1:] = torch.cumsum(m_t, 0)
-    Nn, Ein, nmax = int(node_ptr[-1]), int(edge_ptr[-1]), int(n_t.max())
+    Nn, Ein, nmax, sq = int(node_ptr[-1]), int(edge_ptr[-1]), int(n_t.max()), int((n_t * n_t).sum())
     cat = torch.cat([e.reshape(2, -1).to(torch.int64) for e in edge_lists], dim=1) if Ein else torch.zeros(2, 0, dtype=torch.int64)
     src, dst = cat[0].contiguous().to(dev), cat[1].contiguous().to(dev)
     node_ptr_d, edge_ptr_d = node_ptr.to(dev), edge_ptr.to(dev)
@@ -43,9 +43,10 @@ def encode_edge_lists(node_counts, edge_lists, h, use_rd, self_loop):
     out_edge_ptr = torch.empty(G + 1, dtype=torch.int64, device=dev)
     nnz_ptr = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
     status = torch.zeros(G, dtype=torch.int32, device=dev)
-    work = torch.empty(nv.lib().esc_features_scratch_bytes(G, Nn, Ein), dtype=torch.uint8, device=dev)
+    work = torch.empty(nv.lib().esc_features_scratch_bytes(G, Nn, Ein, sq, nmax, int(bool(use_rd))), dtype=torch.uint8,
+                       device=dev)
     s = nv.stream()
-    nv.call("esc_features_count", nv.ptr(node_ptr_d), nv.ptr(edge_ptr_d), nv.ptr(src), nv.ptr(dst), G, Nn, Ein, nmax,
+    nv.call("esc_features_count", nv.ptr(node_ptr_d), nv.ptr(edge_ptr_d), nv.ptr(src), nv.ptr(dst), G, Nn, Ein, sq, nmax,
             int(h), int(bool(use_rd)), int(bool(self_loop)), nv.ptr(out_edge_ptr), nv.ptr(nnz_ptr), nv.ptr(status),
             nv.ptr(work), s)
     oep = out_edge_ptr.cpu()
@@ -57,7 +58,7 @@ def encode_edge_lists(node_counts, edge_lists, h, use_rd, self_loop):
     pos_enc = torch.empty(Z, dtype=torch.int64, device=dev)
     pos_index = torch.empty(Z, dtype=torch.int64, device=dev)
     pos_batch = torch.empty(Z, dtype=torch.int64, device=dev)
-    nv.call("esc_features_fill", nv.ptr(node_ptr_d), nv.ptr(edge_ptr_d), G, Nn, Ein, nmax, int(h),
+    nv.call("esc_features_fill", nv.ptr(node_ptr_d), nv.ptr(edge_ptr_d), G, Nn, Ein, sq, nmax, int(h),
             int(bool(use_rd)), int(bool(self_loop)), nv.ptr(out_edge_ptr), nv.ptr(nnz_ptr), Eout, nv.ptr(out_src),
             nv.ptr(out_dst), nv.ptr(in_of_out), nv.ptr(pos_enc), nv.ptr(pos_index), nv.ptr(pos_batch),
             nv.ptr(status), nv.ptr(work), s)
@@ -65,8 +66,8 @@ def encode_edge_lists(node_counts, edge_lists, h, use_rd, self_loop):
     if bool((st != 0).any()):
         g = int(torch.nonzero(st)[0])
         raise RuntimeError("create_subgraphs: graph %d cannot be encoded (status %d): a sub-degree >= 200, a "
-                           "resistance-distance bin outside [0,100), an edge code >= 1300, a node id out of "
-                           "range, or an ego-net of more than 96 nodes with use_rd" % (g, int(st[g])))
+                           "resistance-distance bin outside [0,100), an edge code >= 1300 or a node id out of "
+                           "range" % (g, int(st[g])))
     nnz_c = nnz_ptr[:Eout + 1].cpu()
     out_src, out_dst, in_of_out = out_src.cpu(), out_dst.cpu(), in_of_out.cpu()
     pos_enc, pos_index, pos_batch = pos_enc.cpu(), pos_index.cpu(), pos_batch.cpu()
@@ -104,8 +105,9 @@ def _rebuild(data, enc, self_loop):
 
 def _check_args(h, max_nodes_per_hop, subgraph_pretransform):
     if max_nodes_per_hop is not None:
-        raise NotImplementedError("max_nodes_per_hop (random neighbour sampling, reference :235-237) is not "
-                                  "part of the deterministic ESC hot path")
+        raise NotImplementedError("max_nodes_per_hop (reference :235-237: python random.sample on the host RNG, one "
+                                  "sequential draw per root and BFS level) is permanently outside the HIP feature "
+                                  "build; no reference run script sets it")
     if subgraph_pretransform is not None:
         raise NotImplementedError("subgraph_pretransform is the k-GNN baseline hook (reference :109-118)")
     hs = [h] if isinstance(h, int) else list(h)

@@ -407,8 +407,9 @@ int esc_collate_fill(const esc_collate_args* args /* host struct of device point
  * G graphs per call.  node_ptr[G+1] / edge_ptr[G+1]: int64 prefix sums of node and input-edge
  * counts (the InMemoryDataset `slices` layout); src/dst: concatenated int64 edge lists with
  * graph-LOCAL node ids.  If self_loop, every (a,a) is dropped and (i,i), i<n appended at the END
- * (:33-36).  max_nodes = largest graph (sizes the per-edge LDS working set; ego-nets of more than
- * 96 nodes are not supported with use_rd in this revision -> status ESC_ERANGE).
+ * (:33-36).  max_nodes = largest graph (<= 4096; sizes the LDS working sets), sum_nodes_sq = sum over
+ * graphs of n_g^2 (sizes the per-root hop tables).  Ego-nets of any size are encoded: the rd pseudo-inverse of
+ * one of more than 96 nodes runs on a global-memory slab instead of LDS (slower, same result).
  * Pass 1 (_count): out_edge_ptr[G+1] (edges after normalisation) and nnz_ptr[cap+1], cap =
  * total_in_edges (+ total_nodes if self_loop): exclusive scan of per-output-edge nonzero counts
  * (entries past the real edge total repeat the grand total).  The host reads out_edge_ptr[G] and
@@ -417,15 +418,20 @@ int esc_collate_fill(const esc_collate_args* args /* host struct of device point
  * sparse encoding pos_enc / pos_index / pos_batch (int64; pos_batch = graph-local edge id, :143).
  * status[G]: 0, or ESC_ERANGE where the reference's one_hot would raise (degree >= 200, rd bin
  * outside [0,100), edge code >= 1300) or a node id is out of range.
- * work: esc_features_scratch_bytes(...) bytes, must be the SAME buffer for both passes. */
-int64_t esc_features_scratch_bytes(int64_t G, int64_t total_nodes, int64_t total_in_edges);
+ * work: esc_features_scratch_bytes(...) bytes, must be the SAME buffer for both passes (the count pass leaves
+ * the hop tables and the per-edge rd rows in it).
+ * max_nodes_per_hop (k_hop_subgraph :235-237, python random.sample on the host's Mersenne twister, one draw per
+ * root and level in edge order) has no entry point: it is a sequential host-RNG walk, never set by the
+ * reference's run scripts, and is permanently outside this path (the python mirror raises). */
+int64_t esc_features_scratch_bytes(int64_t G, int64_t total_nodes, int64_t total_in_edges, int64_t sum_nodes_sq,
+                                   int64_t max_nodes, int use_rd);
 int esc_features_count(const int64_t* node_ptr, const int64_t* edge_ptr, const int64_t* src,
                        const int64_t* dst, int64_t G, int64_t total_nodes, int64_t total_in_edges,
-                       int64_t max_nodes, int h, int use_rd, int self_loop, int64_t* out_edge_ptr,
-                       int64_t* nnz_ptr, int32_t* status, void* work, void* stream);
+                       int64_t sum_nodes_sq, int64_t max_nodes, int h, int use_rd, int self_loop,
+                       int64_t* out_edge_ptr, int64_t* nnz_ptr, int32_t* status, void* work, void* stream);
 int esc_features_fill(const int64_t* node_ptr, const int64_t* edge_ptr, int64_t G, int64_t total_nodes,
-                      int64_t total_in_edges, int64_t max_nodes, int h, int use_rd, int self_loop,
-                      const int64_t* out_edge_ptr, const int64_t* nnz_ptr, int64_t total_out_edges,
+                      int64_t total_in_edges, int64_t sum_nodes_sq, int64_t max_nodes, int h, int use_rd,
+                      int self_loop, const int64_t* out_edge_ptr, const int64_t* nnz_ptr, int64_t total_out_edges,
                       int64_t* out_src, int64_t* out_dst, int64_t* in_edge_of_out, int64_t* pos_enc,
                       int64_t* pos_index, int64_t* pos_batch, int32_t* status, void* work, void* stream);
 

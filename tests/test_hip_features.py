@@ -94,3 +94,46 @@ def test_larger_graph_and_errors(E):
         encode_edge_lists([2], [torch.tensor([[0], [1]])], 5, False, False)            # h > 4
     with pytest.raises(NotImplementedError):
         E.create_subgraphs(E.Data(x=torch.ones(2, 1), edge_index=torch.tensor([[0], [1]])), 1, max_nodes_per_hop=3)
+
+
+def _hub_ring(n):
+    """node 0 joined to everyone, the others on a ring: every 2-hop ego-net is the whole graph"""
+    pairs = [(0, i) for i in range(1, n)] + [(i, i + 1) for i in range(1, n - 1)] + [(n - 1, 1)]
+    s = np.array([a for a, b in pairs] + [b for a, b in pairs], np.int64)
+    t = np.array([b for a, b in pairs] + [a for a, b in pairs], np.int64)
+    return n, s, t
+
+
+def _regular_like(n, seed):
+    """ring + two random perfect matchings (degree <= 4): 3-hop ego-nets of 50..100 nodes, many distinct ones"""
+    rng = np.random.default_rng(seed)
+    pairs = {(i, (i + 1) % n) for i in range(n)}
+    for _ in range(2):
+        p = rng.permutation(n)
+        pairs |= {(int(min(a, b)), int(max(a, b))) for a, b in zip(p[0::2], p[1::2]) if a != b}
+    pairs = sorted((min(a, b), max(a, b)) for a, b in pairs)
+    s = np.array([a for a, b in pairs] + [b for a, b in pairs], np.int64)
+    t = np.array([b for a, b in pairs] + [a for a, b in pairs], np.int64)
+    return n, s, t
+
+
+@pytest.mark.parametrize("case", ["hub130", "regular104_h3", "regular104_h4", "mol150", "mixed_batch"])
+def test_ego_nets_beyond_lds_with_rd(E, case):
+    """use_rd on ego-nets of more than 96 nodes (ogbg-molhiv holds 222-atom molecules): the pseudo-inverse leaves LDS for
+    a global-memory slab; graphs of > 96 nodes whose ego-nets stay small keep the LDS buckets.  Bit-exact vs the oracle."""
+    from esc_gnn_amd.utils_edge_efficient import encode_edge_lists
+    if case == "hub130":
+        graphs, h, sl = [_hub_ring(130)], 2, True
+    elif case == "regular104_h3":
+        graphs, h, sl = [_regular_like(104, 1)], 3, False
+    elif case == "regular104_h4":
+        graphs, h, sl = [_regular_like(104, 2)], 4, True
+    elif case == "mol150":
+        graphs, h, sl = [gs.molecule_like_graph(3, 150, 150)], 4, True
+    else:
+        graphs, h, sl = [gs.count_shape_graph(41), _hub_ring(100), gs.molecule_like_graph(5), _regular_like(98, 3)], 3, True
+    encs = encode_edge_lists([g[0] for g in graphs], [torch.tensor(np.stack([g[1], g[2]])) for g in graphs], h, True, sl)
+    for i, ((n, s, t), enc) in enumerate(zip(graphs, encs)):
+        want = orc.encode_graph(s, t, n, h, True, sl)
+        _cmp(enc, dict(out_src=want["edge_src"], out_dst=want["edge_dst"], pos_enc=want["pos_enc"],
+                       pos_index=want["pos_index"], pos_batch=want["pos_batch"]), "%s/%d" % (case, i))
