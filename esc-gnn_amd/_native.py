@@ -9,7 +9,7 @@ from ctypes import c_double, c_float, c_int, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libescgnn_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
 
@@ -104,13 +104,21 @@ SIGNATURES = {
     "esc_adam_step_scaled": [P, P, P, P, I64, c_double, c_double, c_double, c_double, I64, P, P],
     "esc_collate_cols": [P, I64, P, I64, P, P, P, P],
     "esc_collate_fill": [POINTER(CollateArgs), P],
+    "esc_embed_fwd": [P, I64, I64, P, I64, P, I64, P, P],
+    "esc_embed_bwd": [P, I64, P, I64, I64, I64, P, P],
+    "esc_zinc_workspace_floats": [P, I64, I64, I64, I64],
+    "esc_zinc_train_step": [P, P, P, I64, P, P, P],
+    "esc_zinc_forward_train": [P, P, P, P, P],
+    "esc_zinc_backward": [P, P, P, P, P],
+    "esc_zinc_predict": [P, P, P, P, P],
     "esc_features_scratch_bytes": [I64, I64, I64, I64, I64, I32],
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
 _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_prof_read_all": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
-        "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64}
+        "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64,
+        "esc_zinc_workspace_floats": c_int64}
 
 
 

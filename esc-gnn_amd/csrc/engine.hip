@@ -30,7 +30,7 @@ struct Arena {
 };
 
 struct BnWs { float *mean, *invstd, *scale, *shift, *nglob; };     // nglob: rows over all ranks (SyncBN)
-struct MlpWs { float *Y0, *Y1; BnWs b0, b1; };
+struct MlpWs { float *Y0, *Y1; BnWs b0, b1; float* A1 = nullptr; };   // A1: materialised hidden activation (ELU models)
 
 struct Layout {
   int64_t N, E, Z, H, L, C0, W;   // W = (L+1)*H
@@ -48,6 +48,9 @@ struct Layout {
   // private scratch of the x_embedding branch (runs on a side stream next to the z/conv chain)
   float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
   float *bn_scratch_e, *col_stats_e;   // the edge stream's own BatchNorm scratch / GEMM-epilogue partials
+  // ZINC variant: node features from a table, [z_emb | edge type] edge-term input, pooled readout
+  float *X0, *dX0, *Zcat, *dZcat, *pooled, *dpool, *Al;
+  int64_t G, D, Wz;                 // graphs, type-embedding width, Wz = H + D
   int64_t total;
 };
 
@@ -115,6 +118,7 @@ struct Ctx {
   std::vector<esc_reduce_job>* jobs = nullptr;   // deferred weight-gradient reduces (main chain only)
   float** slab_cursor = nullptr;
   bool on_edge_stream = false;
+  int act = 1;                                   // 1 ReLU (counting model), 2 ELU (ZINC): materialised activations
 };
 
 // dX + dW tiles now, slab reduce deferred (or immediate when the context has no job list)
@@ -289,14 +293,14 @@ static int bn_backward(const Ctx& c, const float* X, int64_t ldx, const float* Y
                        int64_t M, const BnWs& w, const esc_bn_t& bn, float* dX, int64_t lddx, float* scratch) {
   const int64_t C = c.y.H;
   if (!sync_on(c))
-    return esc_bn_bwd(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, 1, dX, lddx, bn.dgamma, bn.dbeta,
+    return esc_bn_bwd(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, c.act, dX, lddx, bn.dgamma, bn.dbeta,
                       scratch, c.s);
   float* buf = sync_buf(c);
-  ESC_TRY(esc_bn_bwd_sums(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, 1, buf, bn.dgamma, bn.dbeta,
+  ESC_TRY(esc_bn_bwd_sums(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, c.act, buf, bn.dgamma, bn.dbeta,
                           scratch, c.s));
   ESC_TRY(sync_allreduce(c, buf, 2 * C));
   ESC_TRY(esc_bn_sync_coef(buf, C, w.nglob, c.s));
-  return esc_bn_bwd_apply(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, 1, buf, dX, lddx, c.s);
+  return esc_bn_bwd_apply(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, c.act, buf, dX, lddx, c.s);
 }
 
 // Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
@@ -343,7 +347,7 @@ static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const 
 // node-sized training-mode MLPs: no finalize launches — each BatchNorm's partials are merged by its consumer
 static bool fold_ok(const Ctx& c, int64_t M) {
   const int64_t H = c.y.H;
-  return c.train && g_fold && !sync_on(c) && g_gemm_stats && esc_linear_fold_available() && c.jobs != nullptr && !c.on_edge_stream && M > 1 && M <= 4096 && H % 32 == 0 &&
+  return c.act == 1 && c.train && g_fold && !sync_on(c) && g_gemm_stats && esc_linear_fold_available() && c.jobs != nullptr && !c.on_edge_stream && M > 1 && M <= 4096 && H % 32 == 0 &&
          H > 32 && H <= 1024;
 }
 
@@ -359,6 +363,11 @@ static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const f
     return esc_affine_act_fold(w.Y1, H, M, H, &f1, 1, out, ld_out, c.s);
   }
   ESC_TRY(linear_bn(c, A, ld_a, p.lin0, nullptr, nullptr, M, w.Y0, p.bn0, w.b0));
+  if (w.A1) {                                 // activation other than ReLU: the hidden activation is written once
+    ESC_TRY(esc_affine_act(w.Y0, H, M, H, w.b0.scale, w.b0.shift, c.act, w.A1, H, c.s));
+    ESC_TRY(linear_bn(c, w.A1, H, p.lin1, nullptr, nullptr, M, w.Y1, p.bn1, w.b1));
+    return esc_affine_act(w.Y1, H, M, H, w.b1.scale, w.b1.shift, c.act, out, ld_out, c.s);
+  }
   ESC_TRY(linear_bn(c, w.Y0, H, p.lin1, w.b0.scale, w.b0.shift, M, w.Y1, p.bn1, w.b1));
   return esc_affine_act(w.Y1, H, M, H, w.b1.scale, w.b1.shift, 1, out, ld_out, c.s);
 }
@@ -370,6 +379,11 @@ static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const 
   const Layout& y = c.y;
   const int64_t H = y.H;
   ESC_TRY(bn_backward(c, w.Y1, H, out, ld_out, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));
+  if (w.A1) {
+    ESC_TRY(linear_backward(c, y.dT1, H, w.A1, H, nullptr, nullptr, p.lin1, M, y.dT2, H, 0));
+    ESC_TRY(bn_backward(c, w.Y0, H, w.A1, H, y.dT2, H, M, w.b0, p.bn0, y.dT2, H, y.bn_scratch));
+    return linear_backward(c, y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0);
+  }
   ESC_TRY(linear_backward(c, y.dT1, H, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1, M, y.dT2, H, 0));
   ESC_TRY(bn_backward(c, w.Y0, H, nullptr, 0, y.dT2, H, M, w.b0, p.bn0, y.dT2, H, y.bn_scratch));
   return linear_backward(c, y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0);
@@ -593,6 +607,148 @@ static int backward(const Ctx& c, Pending* defer) {
   return ESC_OK;
 }
 
+// =====================================================================================================================
+// ZINC variant (zinc_models.py:504-611): one stream, ELU, materialised activations.  Reuses the helpers above through a
+// Ctx whose count-model pointers are null.
+// =====================================================================================================================
+static Layout plan_layout_zinc(const esc_zinc_gin_t* m, int64_t N, int64_t E, int64_t Z, int64_t G, float* base, bool train) {
+  Layout y{};
+  Arena a{base, 0};
+  const int64_t H = m->hidden, L = m->num_layers, D = m->edge_emb.dim, C0 = m->node_emb.dim;
+  y.N = N; y.E = E; y.Z = Z; y.H = H; y.L = L; y.C0 = C0; y.W = L * H; y.G = G; y.D = D; y.Wz = H + D;
+  y.X0 = a.take(N * C0);
+  y.Zb = a.take(E * H); y.Yz = a.take(E * H); y.zb0 = take_bn(a, H); y.zb1 = take_bn(a, H);
+  y.A0 = a.take(E * H); y.Zcat = a.take(E * y.Wz);
+  for (int l = 0; l < L; ++l) {
+    const int64_t C = l == 0 ? C0 : H;
+    y.e[l] = a.take(E * C);
+    y.agg[l] = a.take(N * C);
+    y.conv[l].Y0 = a.take(N * H); y.conv[l].Y1 = a.take(N * H); y.conv[l].A1 = a.take(N * H);
+    y.conv[l].b0 = take_bn(a, H); y.conv[l].b1 = take_bn(a, H);
+  }
+  y.cat = a.take(N * y.W); y.pooled = a.take(G * y.W); y.Yl = a.take(G * H); y.Al = a.take(G * H); y.bl = take_bn(a, H);
+  y.pred = a.take(G); y.dpred = a.take(G);
+  y.bn_scratch = a.take(esc_bn_scratch(H));
+  y.col_stats = a.take(2 * ((E > N ? E : N) / 32 + 1) * H);
+  y.col_stats_b = a.take(2 * (N / 32 + 1) * H);
+  if (train) {
+    y.dcat = a.take(N * y.W); y.dpool = a.take(G * y.W); y.dAl = a.take(G * H);
+    y.dT1 = a.take(N * H); y.dT2 = a.take(N * H); y.dagg = a.take(N * H); y.dX0 = a.take(N * C0);
+    y.dZcat = a.take(E * y.Wz); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
+    for (int l = 0; l < L; ++l) y.d_e[l] = a.take(E * (l == 0 ? C0 : H));
+    y.deps_part = a.take(N * (L > 0 ? L : 1));
+    y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
+    int64_t sl = esc_linear_bwd_weight_scratch(E, H, H) + 64;                                    // zlin
+    for (int l = 0; l < L; ++l) {
+      const int64_t C = l == 0 ? C0 : H;
+      sl += esc_linear_bwd_weight_scratch(E, C, y.Wz) + esc_linear_bwd_weight_scratch(N, H, H) +
+            esc_linear_bwd_weight_scratch(N, H, C) + 3 * 64;                                       // conv.lin, nn.lin1, nn.lin0
+    }
+    sl += esc_linear_bwd_weight_scratch(G, H, y.W) + esc_linear_bwd_weight_scratch(G, 1, H) + 2 * 64;   // lin1, lin2
+    y.slabs = a.take(sl);
+  }
+  y.total = a.off;
+  return y;
+}
+
+struct ZincCtx {
+  const esc_zinc_gin_t* m;
+  const esc_mol_batch_t* b;
+  Ctx c;                       // helpers' view: layout, stream, job list, act = ELU
+};
+
+static int forward_zinc(const ZincCtx& z) {
+  const esc_zinc_gin_t* m = z.m;
+  const esc_mol_batch_t* b = z.b;
+  const Ctx& c = z.c;
+  const Layout& y = c.y;
+  const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W, G = y.G, D = y.D, Wz = y.Wz, C0 = y.C0;
+  const int act = c.act;
+  // x = node_type_embedding(data.x) (:581)
+  ESC_TRY(esc_embed_fwd(m->node_emb.w, m->node_emb.rows, C0, b->node_type, N, y.X0, C0, nullptr, c.s));
+  // z_emb = z_embedding(ESC bag) (:589-590), written into the first H columns of the edge-term input; the last D
+  // columns are edge_type_embedding(edge_attr) (:591)
+  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, c.s));
+  if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, c.s));
+  ESC_TRY(bn_coeffs(c, y.Zb, H, E, m->zbn0, y.zb0));
+  ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, act, y.A0, H, c.s));
+  ESC_TRY(linear_bn(c, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
+  ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, act, y.Zcat, Wz, c.s));
+  ESC_TRY(esc_embed_fwd(m->edge_emb.w, m->edge_emb.rows, D, b->edge_type, E, y.Zcat + H, Wz, nullptr, c.s));
+  // GINE layers (:593-598): xs[l] -> cat[:, l*H : (l+1)*H]
+  for (int l = 0; l < (int)L; ++l) {
+    const esc_conv_t& cv = m->conv[l];
+    const int64_t C = l == 0 ? C0 : H;
+    const float* hin = l == 0 ? y.X0 : y.cat + (int64_t)(l - 1) * H;
+    const int64_t ld_h = l == 0 ? C0 : W;
+    ESC_TRY(esc_linear_fwd(y.Zcat, Wz, cv.lin.w, Wz, cv.lin.b, nullptr, nullptr, E, C, Wz, y.e[l], C, nullptr, c.s));
+    ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)l * H, W));
+  }
+  // readout (:601-609): global_add_pool -> lin1 -> bn_lin1 -> ELU -> lin2
+  ESC_TRY(esc_segment_pool_fwd(y.cat, W, b->graph_ptr, G, W, 0, y.pooled, W, c.s));
+  ESC_TRY(linear_bn(c, y.pooled, W, m->lin1, nullptr, nullptr, G, y.Yl, m->bn_lin1, y.bl));
+  ESC_TRY(esc_affine_act(y.Yl, H, G, H, y.bl.scale, y.bl.shift, act, y.Al, H, c.s));
+  return esc_linear_fwd(y.Al, H, m->lin2.w, H, m->lin2.b, nullptr, nullptr, G, 1, H, y.pred, 1, nullptr, c.s);
+}
+
+static int backward_zinc(const ZincCtx& z) {
+  const esc_zinc_gin_t* m = z.m;
+  const esc_mol_batch_t* b = z.b;
+  const Ctx& c = z.c;
+  const Layout& y = c.y;
+  const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W, G = y.G, D = y.D, Wz = y.Wz, C0 = y.C0;
+  ESC_TRY(linear_backward(c, y.dpred, 1, y.Al, H, nullptr, nullptr, m->lin2, G, y.dAl, H, 0));
+  ESC_TRY(bn_backward(c, y.Yl, H, y.Al, H, y.dAl, H, G, y.bl, m->bn_lin1, y.dAl, H, y.bn_scratch));
+  ESC_TRY(linear_backward(c, y.dAl, H, y.pooled, W, nullptr, nullptr, m->lin1, G, y.dpool, W, 0));
+  ESC_TRY(esc_segment_pool_bwd(y.dpool, W, b->graph_ptr, G, W, 0, y.dcat, W, c.s));
+  std::vector<esc_sum_job> eps_jobs;
+  for (int l = (int)L - 1; l >= 0; --l) {
+    const esc_conv_t& cv = m->conv[l];
+    const int64_t C = l == 0 ? C0 : H;
+    const float* hin = l == 0 ? y.X0 : y.cat + (int64_t)(l - 1) * H;
+    const int64_t ld_h = l == 0 ? C0 : W;
+    ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)l * H, W, y.dcat + (int64_t)l * H, W, y.dagg, C));
+    float* dx = l == 0 ? y.dX0 : y.dcat + (int64_t)(l - 1) * H;
+    ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
+                                   y.d_e[l], C, dx, l == 0 ? C0 : W, l == 0 ? 0 : 1, y.deps_part + (int64_t)l * N, c.s));
+    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
+    ESC_TRY(linear_backward(c, y.d_e[l], C, y.Zcat, Wz, nullptr, nullptr, cv.lin, E, y.dZcat, Wz, l == (int)L - 1 ? 0 : 1));
+  }
+  ESC_TRY(esc_embed_bwd(y.dX0, C0, b->node_type, N, m->node_emb.rows, C0, m->node_emb.dw, c.s));
+  ESC_TRY(esc_embed_bwd(y.dZcat + H, Wz, b->edge_type, E, m->edge_emb.rows, D, m->edge_emb.dw, c.s));
+  // z_embedding + bag
+  ESC_TRY(bn_backward(c, y.Yz, H, y.Zcat, Wz, y.dZcat, Wz, E, y.zb1, m->zbn1, y.dZemb, H, y.bn_scratch));
+  ESC_TRY(linear_backward(c, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
+  ESC_TRY(bn_backward(c, y.Zb, H, y.A0, H, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, y.bn_scratch));
+  ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
+                                 m->dz_table, y.bag_scratch, c.s));
+  if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
+  if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
+  return ESC_OK;
+}
+
+static int check_zinc(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, const float* ws, bool train, bool need_y) {
+  ESC_REQUIRE(m && b && ws, "esc_zinc: null pointer");
+  ESC_REQUIRE(m->num_layers >= 1 && m->num_layers <= ESC_MAX_LAYERS, "esc_zinc: %ld layers unsupported", (long)m->num_layers);
+  ESC_REQUIRE(m->hidden > 0 && m->hidden % 4 == 0, "esc_zinc: hidden must be a multiple of 4");
+  ESC_REQUIRE(m->node_emb.dim > 0 && m->node_emb.dim % 4 == 0 && m->edge_emb.dim > 0 && m->edge_emb.dim % 4 == 0,
+              "esc_zinc: embedding widths must be multiples of 4");
+  ESC_REQUIRE(m->conv[0].lin.in_dim == m->hidden + m->edge_emb.dim && m->conv[0].lin.out_dim == m->node_emb.dim,
+              "esc_zinc: conv1.lin must map hidden + edge width to the node width");
+  ESC_REQUIRE(b->N >= 2 && b->E >= 2 && b->Z >= 0 && b->G >= 2, "esc_zinc: batch needs >= 2 nodes, edges and graphs (BatchNorm statistics)");
+  ESC_REQUIRE(b->node_type && b->edge_type && b->graph_ptr && b->in_ptr && b->row_ptr &&
+              (!train || ((b->y || !need_y) && b->out_ptr && b->col_ptr)), "esc_zinc: null batch arrays");
+  ESC_REQUIRE(aligned16(ws), "esc_zinc: workspace must be 16-byte aligned");
+  return ESC_OK;
+}
+
+static ZincCtx make_zinc(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* ws, void* stream, bool train) {
+  ZincCtx z{m, b, Ctx{nullptr, nullptr, plan_layout_zinc(m, b->N, b->E, b->Z, b->G, ws, train), stream, train}};
+  z.c.act = 2;
+  return z;
+}
+
 static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* ws, bool train, bool need_y = true) {
   ESC_REQUIRE(m && b && ws, "esc_engine: null pointer");
   ESC_REQUIRE(m->num_layers >= 1 && m->num_layers <= ESC_MAX_LAYERS, "esc_engine: %ld layers unsupported", (long)m->num_layers);
@@ -765,6 +921,70 @@ int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* w
     return ESC_ELAUNCH;
   }
   return ESC_OK;
+}
+
+// ---- ZINC variant ------------------------------------------------------------------------------------------------------
+int64_t esc_zinc_workspace_floats(const esc_zinc_gin_t* m, int64_t N, int64_t E, int64_t Z, int64_t G) {
+  if (!m || N < 0 || E < 0 || Z < 0 || G < 0) return -1;
+  return plan_layout_zinc(m, N, E, Z, G, nullptr, true).total + 64;
+}
+
+static int copy_floats(float* dst, const float* src, int64_t n, void* stream, const char* what) {
+  if (hipMemcpyAsync(dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    set_error("%s: copy failed", what);
+    return ESC_ELAUNCH;
+  }
+  return ESC_OK;
+}
+
+int esc_zinc_train_step(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, int64_t loss_denom,
+                        float* loss, float* pred, void* stream) {
+  int rc = check_zinc(m, b, workspace, true, true);
+  if (rc) return rc;
+  ESC_REQUIRE(loss, "esc_zinc_train_step: null loss pointer");
+  ZincCtx z = make_zinc(m, b, workspace, stream, true);
+  std::vector<esc_reduce_job> jobs;
+  jobs.reserve(ESC_MAX_REDUCE_JOBS);
+  float* cursor = z.c.y.slabs;
+  if (3 * m->num_layers + 3 <= ESC_MAX_REDUCE_JOBS) { z.c.jobs = &jobs; z.c.slab_cursor = &cursor; }
+  ESC_TRY(forward_zinc(z));
+  ESC_TRY(esc_l1_loss(z.c.y.pred, b->y, b->G, loss_denom > 0 ? loss_denom : b->G, 1.0f, loss, z.c.y.dpred, stream));
+  if (pred) ESC_TRY(copy_floats(pred, z.c.y.pred, b->G, stream, "esc_zinc_train_step"));
+  return backward_zinc(z);
+}
+
+int esc_zinc_forward_train(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, float* pred, void* stream) {
+  int rc = check_zinc(m, b, workspace, true, false);
+  if (rc) return rc;
+  ESC_REQUIRE(pred, "esc_zinc_forward_train: null output");
+  ZincCtx z = make_zinc(m, b, workspace, stream, true);
+  std::vector<esc_reduce_job> jobs;            // only marks the main chain (statistics from the GEMM epilogues)
+  float* cursor = z.c.y.slabs;
+  z.c.jobs = &jobs; z.c.slab_cursor = &cursor;
+  ESC_TRY(forward_zinc(z));
+  return copy_floats(pred, z.c.y.pred, b->G, stream, "esc_zinc_forward_train");
+}
+
+int esc_zinc_backward(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, const float* dpred, void* stream) {
+  int rc = check_zinc(m, b, workspace, true, false);
+  if (rc) return rc;
+  ESC_REQUIRE(dpred, "esc_zinc_backward: null gradient");
+  ZincCtx z = make_zinc(m, b, workspace, stream, true);
+  std::vector<esc_reduce_job> jobs;
+  jobs.reserve(ESC_MAX_REDUCE_JOBS);
+  float* cursor = z.c.y.slabs;
+  if (3 * m->num_layers + 3 <= ESC_MAX_REDUCE_JOBS) { z.c.jobs = &jobs; z.c.slab_cursor = &cursor; }
+  ESC_TRY(copy_floats(z.c.y.dpred, dpred, b->G, stream, "esc_zinc_backward"));
+  return backward_zinc(z);
+}
+
+int esc_zinc_predict(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, float* pred, void* stream) {
+  int rc = check_zinc(m, b, workspace, false, false);
+  if (rc) return rc;
+  ESC_REQUIRE(pred, "esc_zinc_predict: null output");
+  ZincCtx z = make_zinc(m, b, workspace, stream, false);
+  ESC_TRY(forward_zinc(z));
+  return copy_floats(pred, z.c.y.pred, b->G, stream, "esc_zinc_predict");
 }
 
 }  // extern "C"

@@ -80,7 +80,7 @@ unsigned* tickets(int n) {
 
 extern "C" {
 
-int esc_abi_version(void) { return 1; }
+int esc_abi_version(void) { return 2; }   // 2: esc_features_* take sum_nodes_sq; esc_zinc_*, esc_embed_*
 const char* esc_last_error(void) { return esc::g_err; }
 
 int esc_prof_enable(int kind, int on) {

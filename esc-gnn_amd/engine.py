@@ -48,6 +48,24 @@ class _Batch(ctypes.Structure):
                                          "row_ptr", "bag_idx", "bag_val", "col_ptr", "col_row", "col_val", "col_col")])
 
 
+class _Embed(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("dw", c_void_p), ("rows", c_int64), ("dim", c_int64)]
+
+
+class _ZincModel(ctypes.Structure):
+    _fields_ = [("num_layers", c_int64), ("hidden", c_int64), ("z_rows", c_int64),
+                ("z_table", c_void_p), ("dz_table", c_void_p),
+                ("zbn0", _BN), ("zlin", _Linear), ("zbn1", _BN), ("node_emb", _Embed), ("edge_emb", _Embed),
+                ("conv", _Conv * MAX_LAYERS), ("lin1", _Linear), ("bn_lin1", _BN), ("lin2", _Linear)]
+
+
+class _MolBatch(ctypes.Structure):
+    _fields_ = ([("N", c_int64), ("E", c_int64), ("Z", c_int64), ("G", c_int64), ("node_type", c_void_p),
+                 ("edge_type", c_void_p), ("y", c_void_p), ("graph_ptr", c_void_p)] +
+                [(n, c_void_p) for n in ("in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst",
+                                         "row_ptr", "bag_idx", "bag_val", "col_ptr", "col_row", "col_val", "col_col")])
+
+
 def _grad_ptr(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p.data)
@@ -257,7 +275,8 @@ class _NodeCache(object):
         self.counters = [m.num_batches_tracked for m in model.modules()
                          if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
         index = {id(p): i for i, p in enumerate(self.params)}
-        self.template = describe(model, lambda p: self.MARK + index[id(p)])
+        describe_fn = getattr(self, "_describe", describe)
+        self.template = describe_fn(model, lambda p: self.MARK + index[id(p)])
         words = np.frombuffer(self.template, dtype=np.uint64)
         hits = np.nonzero((words >= self.MARK) & (words < self.MARK + len(self.params)))[0]
         self.slots = hits                                                  # word positions of the gradient pointers
@@ -274,7 +293,7 @@ class _NodeCache(object):
 
     def descriptor(self, grad_base):
         import numpy as np
-        d = _Model.from_buffer_copy(self.template)
+        d = getattr(self, "_struct", _Model).from_buffer_copy(self.template)
         np.frombuffer(d, dtype=np.uint64)[self.slots] = np.uint64(grad_base) + self.byte_offsets
         return d
 
@@ -328,3 +347,171 @@ def engine_forward(model, data):
         install_collective(model.lin2.in_features, model.lin1.weight.device, groups[0])
     cache = _node_cache(model)
     return _EngineNode.apply(model, data, cache, *cache.params)
+
+
+# ---- ZINC variant (zinc_models.NestedGIN_eff; csrc/engine.hip esc_zinc_*) ---------------------------------------------
+def _embed(mod, gp=_grad_ptr):
+    s = _Embed()
+    s.w, s.dw = mod.weight.data_ptr(), gp(mod.weight)
+    s.rows, s.dim = mod.num_embeddings, mod.embedding_dim
+    return s
+
+
+def describe_zinc(m, gp=_grad_ptr):
+    """esc_zinc_gin_t of a zinc_models.NestedGIN_eff module"""
+    d = _ZincModel()
+    convs = [m.conv1] + list(m.convs)
+    if len(convs) > MAX_LAYERS:
+        raise ValueError("at most %d layers" % MAX_LAYERS)
+    d.num_layers, d.hidden, d.z_rows = len(convs), m.lin2.in_features, m.z_initial.num_embeddings
+    d.z_table, d.dz_table = m.z_initial.weight.data_ptr(), gp(m.z_initial.weight)
+    d.zbn0, d.zlin, d.zbn1 = _bn(m.z_embedding[1], gp), _lin(m.z_embedding[3], gp), _bn(m.z_embedding[5], gp)
+    d.node_emb, d.edge_emb = _embed(m.node_type_embedding, gp), _embed(m.edge_type_embedding, gp)
+    for i, cv in enumerate(convs):
+        c = _Conv()
+        c.eps, c.deps = cv.eps.data_ptr(), gp(cv.eps)
+        c.nn, c.lin = _mlp(cv.nn, gp), _lin(cv.lin, gp)
+        d.conv[i] = c
+    d.lin1, d.bn_lin1, d.lin2 = _lin(m.lin1, gp), _bn(m.bn_lin1, gp), _lin(m.lin2, gp)
+    return d
+
+
+def zinc_engine_supports(m, data=None):
+    """what esc_zinc_* covers: the run_zinc configuration (dropout 0, per-rank BatchNorm statistics), sparse ESC bag,
+    at least two graphs in the batch (the reference skips bn_lin1 for one, zinc_models.py:603-604)"""
+    if m.dropout != 0 or m.lin1.weight.device.type != "cuda" or m.lin2.out_features != 1 or _sync_groups(m):
+        return False
+    if data is not None:
+        if "edge_pos" in data or "pos_batch" not in data or data.edge_index.size(1) < 2 or data["edge_attr"] is None:
+            return False
+    return True
+
+
+def zinc_engine_ready(m, data):
+    """zinc_engine_supports and at least two graphs in this batch"""
+    if not zinc_engine_supports(m, data):
+        return False
+    from .plan import graph_ptr_of
+    from .run_graphcount import Z_TABLE_ROWS
+    return graph_ptr_of(data, plan_of(data, Z_TABLE_ROWS))[1] >= 2
+
+
+def _zinc_batch(model, data, need_y):
+    from .plan import graph_ptr_of
+    from .run_graphcount import Z_TABLE_ROWS
+    dev = model.lin1.weight.device
+    if data.edge_index.device != dev:
+        data.to(dev)
+    plan = plan_of(data, Z_TABLE_ROWS)
+    gptr, G = graph_ptr_of(data, plan)
+    b = _MolBatch()
+    b.N, b.E, b.Z, b.G = plan.num_nodes, plan.num_edges, plan.nnz, G
+    nt = data.x.reshape(-1)
+    et = data.edge_attr.reshape(-1)
+    nt = nt if (nt.dtype == torch.int64 and nt.is_contiguous()) else nt.to(torch.int64).contiguous()
+    et = et if (et.dtype == torch.int64 and et.is_contiguous()) else et.to(torch.int64).contiguous()
+    if nt.numel() != b.N or et.numel() != b.E:
+        raise ValueError("ZINC engine: expected one type id per node and per edge")
+    b.node_type, b.edge_type, b.graph_ptr = nt.data_ptr(), et.data_ptr(), gptr.data_ptr()
+    y = None
+    if need_y:
+        y = data.y.reshape(-1)
+        y = y if (y.dtype == torch.float32 and y.is_contiguous()) else y.float().contiguous()
+        if y.numel() != G:
+            raise ValueError("ZINC engine: expected one target per graph")
+        b.y = y.data_ptr()
+    for f in ("in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst", "row_ptr", "bag_idx", "bag_val",
+              "col_ptr", "col_row", "col_val", "col_col"):
+        setattr(b, f, getattr(plan, f).data_ptr())
+    return b, (nt, et, y, plan, gptr)
+
+
+class ZincStepEngine(object):
+    """Training / eval step of zinc_models.NestedGIN_eff as ONE call (esc_zinc_train_step / esc_zinc_predict): same
+    parameters, `.grad` slots and BatchNorm buffers as the module, like StepEngine for the counting model."""
+
+    def __init__(self, model):
+        if not zinc_engine_supports(model):
+            raise NotImplementedError("ZincStepEngine covers dropout 0, lin2 -> 1 output, per-rank BatchNorm on the HIP device")
+        self.model = model
+        self._ws = None
+        self._bn_counters = [m.num_batches_tracked for m in model.modules()
+                             if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
+        self.refresh()
+
+    def refresh(self):
+        self._desc = describe_zinc(self.model)
+
+    def _workspace(self, b):
+        need = nv.lib().esc_zinc_workspace_floats(ctypes.byref(self._desc), b.N, b.E, b.Z, b.G)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25), dtype=torch.float32, device=self.model.lin1.weight.device)
+        return self._ws
+
+    def train_step(self, data, loss_denom=None, return_pred=False):
+        """forward + L1 over the graphs + backward; gradients land in the parameters' .grad (overwritten)"""
+        dev = self.model.lin1.weight.device
+        b, keep = _zinc_batch(self.model, data, True)
+        ws = self._workspace(b)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        pred = torch.empty(b.G, dtype=torch.float32, device=dev) if return_pred else None
+        nv.call("esc_zinc_train_step", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), int(loss_denom or 0),
+                loss.data_ptr(), nv.ptr(pred), nv.stream())
+        if self._bn_counters:
+            torch._foreach_add_(self._bn_counters, 1)
+        return (loss.view(()), pred.view(-1, 1)) if return_pred else loss.view(())
+
+    @torch.no_grad()
+    def predict(self, data):
+        dev = self.model.lin1.weight.device
+        b, keep = _zinc_batch(self.model, data, False)
+        ws = self._workspace(b)
+        pred = torch.empty(b.G, dtype=torch.float32, device=dev)
+        nv.call("esc_zinc_predict", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+        return pred.view(-1, 1)
+
+
+class _ZincNodeCache(_NodeCache):
+    def __init__(self, model):
+        self._describe, self._struct = describe_zinc, _ZincModel
+        super().__init__(model)
+
+
+class _ZincEngineNode(torch.autograd.Function):
+    """`model(batch)` of a training-mode ZINC NestedGIN_eff as one autograd node (esc_zinc_forward_train / _backward)"""
+
+    @staticmethod
+    def forward(ctx, model, data, cache, *params):
+        dev = model.lin1.weight.device
+        b, keep = _zinc_batch(model, data, False)
+        desc = cache.descriptor(0)
+        need = nv.lib().esc_zinc_workspace_floats(ctypes.byref(desc), b.N, b.E, b.Z, b.G)
+        ws = torch.empty(int(need), dtype=torch.float32, device=dev)
+        pred = torch.empty(b.G, dtype=torch.float32, device=dev)
+        nv.call("esc_zinc_forward_train", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+        if cache.counters:
+            torch._foreach_add_(cache.counters, 1)
+        ctx.cache, ctx.b, ctx.keep, ctx.ws = cache, b, keep, ws
+        return pred.view(-1, 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dpred):
+        cache = ctx.cache
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)
+        desc = cache.descriptor(flat.data_ptr())
+        g = dpred.reshape(-1)
+        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        nv.call("esc_zinc_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+        grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
+                      for p, o in zip(cache.params, cache.offsets))
+        ctx.ws = ctx.keep = None
+        return (None, None, None) + grads
+
+
+def zinc_engine_forward(model, data):
+    c = model.__dict__.get("_esc_node_cache")
+    if c is None or not c.valid():
+        c = _ZincNodeCache(model)
+        model.__dict__["_esc_node_cache"] = c
+    return _ZincEngineNode.apply(model, data, c, *c.params)

@@ -50,12 +50,15 @@ class BatchPlan(object):
         self.num_edges = kw["num_edges"]
         self.nnz = kw["nnz"]
         self.n_cols = kw.get("n_cols", 1800)
+        self.graph_ptr, self.num_graphs = None, None      # node range of every graph: set by the device collate / graph_ptr_of
 
     def to(self, device):
         for f in self.FIELDS:
             v = getattr(self, f)
             if v is not None:
                 setattr(self, f, v.to(device))
+        if self.graph_ptr is not None:
+            self.graph_ptr = self.graph_ptr.to(device)
         return self
 
     @staticmethod
@@ -110,3 +113,15 @@ def plan_of(data, n_cols=1800):
     plan._key = key
     object.__setattr__(data, "_esc_plan", plan)
     return plan
+
+
+def graph_ptr_of(data, plan):
+    """int32 [G+1] node range of every graph of a batch (its `batch` vector is non-decreasing) and G; from the device
+    collate when the batch came from there, else one esc_plan_csr call, cached on the plan."""
+    if plan.graph_ptr is None:
+        batch = data.batch
+        G = int(batch[-1].item()) + 1 if batch.numel() else 0
+        if batch.numel() > 1 and not bool((batch[1:] >= batch[:-1]).all()):
+            raise ValueError("the batch vector must be non-decreasing")
+        plan.graph_ptr, plan.num_graphs = _csr(batch, max(G, 1), want_perm=False)[0], G
+    return plan.graph_ptr, plan.num_graphs

@@ -24,6 +24,7 @@ class NestedGIN_eff(torch.nn.Module):
     def __init__(self, dataset, num_layers, concat=False, use_pos=False, use_max_dist=False, RNI=False, **kwargs):
         super().__init__()
         self.use_z = True
+        self.step_engine = True       # training-mode forward through the whole-step engine when the batch allows it
         hidden, dropout = 256, 0.0
         self.dropout = dropout
         self.z_initial = torch.nn.Embedding(Z_TABLE_ROWS, hidden)
@@ -55,6 +56,10 @@ class NestedGIN_eff(torch.nn.Module):
 
     def forward(self, data):
         data.to(self.lin1.weight.device)
+        if self.training and torch.is_grad_enabled() and self.step_engine:
+            from .engine import zinc_engine_forward, zinc_engine_ready
+            if zinc_engine_ready(self, data):
+                return zinc_engine_forward(self, data)     # the whole step as one autograd node (csrc/engine.hip esc_zinc_*)
         x, edge_index, batch = self.node_type_embedding(data.x.view(-1)), data.edge_index, data.batch
         plan = plan_of(data, Z_TABLE_ROWS)
         if "edge_pos" in data:

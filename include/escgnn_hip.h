@@ -366,6 +366,44 @@ int esc_engine_backward(const esc_nested_gin_t* m, const esc_batch_t* b, float* 
 int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* workspace, float* pred,
                        void* stream);
 
+/* ---- whole-step engine, ZINC variant: NestedGIN_eff of zinc_models.py:504-611 (BASELINE config 4) -------------
+ * x = node_type_embedding(x) (:581), z = z_embedding(ESC bag) with ELU (:513-522,:589-590), edge term input
+ * [z_emb | edge_type_embedding(edge_attr)] (:591, edge_dim = hidden + 32), L GINEConv layers with ELU MLPs (:593-598),
+ * readout global_add_pool(cat(xs)) -> lin1 -> BatchNorm -> ELU -> lin2 (:601-609), L1 loss over the graphs (run_zinc.py).
+ * Same conventions as esc_engine_*: gradients are WRITTEN into the d* slots; the batch needs >= 2 graphs
+ * (the reference skips bn_lin1 for a single graph, :603-604 — that case stays on the per-op path).
+ * Activations are materialised (the GEMM prologue of the counting engine is ReLU-only); one stream. */
+typedef struct esc_embed_t { const float* w; float* dw; int64_t rows, dim; } esc_embed_t;
+typedef struct esc_zinc_gin_t {
+  int64_t num_layers, hidden, z_rows;
+  const float* z_table; float* dz_table;                 /* z_initial.weight */
+  esc_bn_t zbn0; esc_linear_t zlin; esc_bn_t zbn1;       /* z_embedding.{1,3,5} */
+  esc_embed_t node_emb, edge_emb;                        /* node_type_embedding, edge_type_embedding */
+  esc_conv_t conv[ESC_MAX_LAYERS];                       /* conv1, convs.*; conv.lin.in_dim = hidden + edge_emb.dim */
+  esc_linear_t lin1; esc_bn_t bn_lin1; esc_linear_t lin2;
+} esc_zinc_gin_t;
+typedef struct esc_mol_batch_t {
+  int64_t N, E, Z, G;
+  const int64_t* node_type; const int64_t* edge_type;    /* [N], [E]: data.x, data.edge_attr flattened */
+  const float* y;                                        /* [G] (train_step only) */
+  const int32_t* graph_ptr;                              /* [G+1]: node range of every graph (batch is sorted) */
+  const int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
+  const int32_t *row_ptr, *bag_idx, *bag_val, *col_ptr, *col_row, *col_val, *col_col;
+} esc_mol_batch_t;
+int64_t esc_zinc_workspace_floats(const esc_zinc_gin_t* m, int64_t N, int64_t E, int64_t Z, int64_t G);
+/* loss[0] = sum|pred-y| / loss_denom (loss_denom <= 0: G).  pred (may be NULL): float[G]. */
+int esc_zinc_train_step(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, int64_t loss_denom,
+                        float* loss, float* pred, void* stream);
+int esc_zinc_forward_train(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, float* pred, void* stream);
+int esc_zinc_backward(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, const float* dpred, void* stream);
+int esc_zinc_predict(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, float* pred, void* stream);
+/* lookups in small embedding tables (rows <= 4096): out[i,:] = table[idx[i],:] (out-of-range index: zero row, *bad_flag
+ * = 1 when given); dtable[r,:] = sum over i with idx[i] == r of g[i,:] in a fixed order (one workgroup per table row) */
+int esc_embed_fwd(const float* table, int64_t rows, int64_t C, const int64_t* idx, int64_t M, float* out, int64_t ld_out,
+                  int32_t* bad_flag, void* stream);
+int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, int64_t rows, int64_t C, float* dtable,
+                  void* stream);
+
 /* ---- a-5 collate (batch.py:25-149): gather B graphs out of the HBM-resident dataset store ------
  * The store keeps the reference's InMemoryDataset layout (per-key concatenation + slice pointers,
  * GraphCountDataset.py:119-120) plus views sorted ONCE at build time (suffix _all):

@@ -209,9 +209,11 @@ def test_sr_variant_against_reference_golden():
         _close(p.grad, torch.tensor(z["grad/" + n]), "grad " + n, tol=1e-4)
 
 
-def test_zinc_variant_against_reference_golden():
+@pytest.mark.parametrize("step_engine", [False, True], ids=["per_op", "engine"])
+def test_zinc_variant_against_reference_golden(step_engine):
     """esc_gnn_amd.zinc_models.NestedGIN_eff (ELU-fused BatchNorm kernels, embeddings through the bag kernels,
-    [z_emb | edge_type] edge term, HIP add-pool) vs tests/golden/model_zinc.npz and an fp64 oracle."""
+    [z_emb | edge_type] edge term, HIP add-pool) vs tests/golden/model_zinc.npz and an fp64 oracle — through the per-op
+    autograd path and through the whole-step engine (csrc/engine.hip esc_zinc_*, one autograd node)."""
     require_gpu()
     import copy
     import esc_gnn_amd as E
@@ -224,10 +226,12 @@ def test_zinc_variant_against_reference_golden():
     assert list(m.state_dict().keys()) == [str(k) for k in z["keys"]]
     m.load_state_dict(ref.state_dict())
     m = m.to("cuda:0").train()
+    m.step_engine = step_engine
     _, b, _ = load_collate("zinc3")
     bt = {k: torch.tensor(v) for k, v in b.items()}
     data = E.Data(**{k: v.clone() for k, v in bt.items()})
     out = m(data)
+    assert (type(out.grad_fn).__name__ == "_ZincEngineNodeBackward") == step_engine
     loss = E.ops.l1_loss(out, bt["y"].float().to("cuda:0"))
     loss.backward()
     _close(out, torch.tensor(z["pred"]), "zinc predictions")
@@ -381,3 +385,44 @@ def test_gineplus_against_reference_class_golden(which):
         _close(got, want, "%s dx%d" % (which, i))
     for n, p in conv.named_parameters():
         _close(p.grad, torch.tensor(g["%s_grad_%s" % (which, n)]), "%s grad %s" % (which, n), tol=2e-5)
+
+
+def test_zinc_step_engine_train_step_and_predict():
+    """ZincStepEngine.train_step (forward + L1 + backward in one call) and .predict against the per-op path of the same
+    module: loss, predictions, every gradient, BatchNorm running statistics; eval-mode predictions."""
+    require_gpu()
+    import copy
+    import esc_gnn_amd as E
+    from esc_gnn_amd.engine import ZincStepEngine
+    from esc_gnn_amd.zinc_models import NestedGIN_eff as ZincModel
+    torch.manual_seed(3)
+    _, b, _ = load_collate("zinc3")
+    bt = {k: torch.tensor(v) for k, v in b.items()}
+    m1 = ZincModel(None, 3).to("cuda:0").train()
+    m2 = copy.deepcopy(m1)
+    m1.step_engine = False
+    d1 = E.Data(**{k: v.clone() for k, v in bt.items()})
+    out = m1(d1)
+    loss1 = E.ops.l1_loss(out, bt["y"].float().to("cuda:0"))
+    loss1.backward()
+    eng = ZincStepEngine(m2)
+    d2 = E.Data(**{k: v.clone() for k, v in bt.items()})
+    loss2, pred2 = eng.train_step(d2, return_pred=True)
+    _close(pred2, out.detach().cpu(), "engine predictions vs per-op")
+    assert abs(float(loss1.detach()) - float(loss2)) <= 1e-5 * max(1.0, abs(float(loss1.detach())))
+    g1 = dict(m1.named_parameters())
+    for n, p in m2.named_parameters():
+        ref = g1[n].grad.cpu()
+        diff = (p.grad.cpu() - ref)
+        sc = max(1.0, float(ref.abs().max()))
+        ok = float(diff.abs().max()) / sc <= 2e-5 or float(diff.norm()) / max(float(ref.norm()), 1e-12) <= 5e-3   # ReLU-kink tie in the aggregate
+        assert ok, "grad %s: %.3g" % (n, float(diff.abs().max()) / sc)
+    for (n, a), (_, c) in zip(m1.named_buffers(), m2.named_buffers()):
+        if a.is_floating_point():
+            _close(c, a.cpu(), "buffer " + n)
+        else:
+            assert torch.equal(a, c), n
+    m1.eval(); m2.eval()
+    with torch.no_grad():
+        e1 = m1(E.Data(**{k: v.clone() for k, v in bt.items()}))
+    _close(eng.predict(E.Data(**{k: v.clone() for k, v in bt.items()})), e1.cpu(), "eval predictions")
