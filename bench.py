@@ -215,6 +215,22 @@ def main():
             n, ms = nv.prof_read(f)
             breakdown[f] = dict(launches_per_step=n / k_extra, ms_per_step=ms / k_extra)
 
+    # the same Linear kernels with the step on ONE stream: each launch has the CUs to itself, so this is what the GEMM
+    # kernels do alone; the figure above is what they do while the other pipeline's kernels share the machine
+    linear_one_stream_ms = None
+    if not args.no_breakdown and args.path == "engine" and world == 1:
+        nv.call("esc_engine_set_side_stream", 0)
+        for i in range(2):
+            step(i)
+        nv.prof_reset("linear")
+        nv.prof_enable("linear", True)
+        for i in range(5):
+            step(i)
+        torch.cuda.synchronize()
+        nv.prof_enable("linear", False)
+        linear_one_stream_ms = nv.prof_read("linear")[1] / 5
+        nv.call("esc_engine_set_side_stream", 2 if args.streams is None else args.streams)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -265,6 +281,13 @@ def main():
                                              "durations summed while both pipelines share the CUs", bound="mfma",
                                       achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                       frac=round(tf / MFMA_F32_PEAK_TF, 4), flops_per_step=int(fl))
+        if linear_one_stream_ms:
+            tf1 = fl / (linear_one_stream_ms * 1e-3) / 1e12
+            extra["roofline_mfma"].update(
+                achieved_one_stream=round(tf1, 2), frac_one_stream=round(tf1 / MFMA_F32_PEAK_TF, 4),
+                linear_ms_per_step_one_stream=round(linear_one_stream_ms, 4),
+                note="frac: launch durations inside the two-stream step (kernels of the other pipeline share the CUs); "
+                     "frac_one_stream: the same launches of the same step with both pipelines on one stream (each kernel alone)")
     cpu = cpu_baseline(args, graphs) if (args.cpu_seconds > 0 and world == 1) else None   # rank 0, N=1 only
 
     out = {

@@ -111,6 +111,17 @@ SIGNATURES = {
     "esc_zinc_forward_train": [P, P, P, P, P],
     "esc_zinc_backward": [P, P, P, P, P],
     "esc_zinc_predict": [P, P, P, P, P],
+    "esc_segment_broadcast_add": [P, I64, P, I64, P, I64, I64, P, I64, P],
+    "esc_dropout_fwd": [P, I64, I64, I64, ctypes.c_float, ctypes.c_uint64, P, I64, P, I64, P, P],
+    "esc_dropout_bwd": [P, I64, I64, I64, ctypes.c_float, P, P, I64, P, I64, P],
+    "esc_table_pack": [P, I64, P, P],
+    "esc_table_unpack_grad": [P, I64, P, P],
+    "esc_bag_fwd_acc": [P, I64, P, P, P, I64, P, I64, P],
+    "esc_ogb_workspace_floats": [P, I64, I64, I64, I64, I64, I64],
+    "esc_ogb_train_step": [P, P, P, I64, P, P, P],
+    "esc_ogb_forward_train": [P, P, P, P, P],
+    "esc_ogb_backward": [P, P, P, P, P],
+    "esc_ogb_predict": [P, P, P, P, P],
     "esc_features_scratch_bytes": [I64, I64, I64, I64, I64, I32],
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
@@ -118,7 +129,7 @@ SIGNATURES = {
 _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_prof_read_all": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64,
-        "esc_zinc_workspace_floats": c_int64}
+        "esc_zinc_workspace_floats": c_int64, "esc_ogb_workspace_floats": c_int64}
 
 
 

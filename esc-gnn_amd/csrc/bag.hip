@@ -22,7 +22,7 @@ namespace esc {
 // Bitwise contract: out = (((0 + w0*v0) + w1*v1) + ...) with separately rounded products, i.e.
 // what a sequential scatter_add_ of the rounded products gives.  __fmul_rn/__fadd_rn are never
 // contracted into an fma.
-template <int VEC>
+template <int VEC, bool ACC = false>
 __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ table, int H,
                                                       const int* __restrict__ row_ptr,
                                                       const int* __restrict__ idx,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
   for (int c = lane * VEC; c < H; c += WAVE * VEC) {
     float acc[VEC];
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+    for (int t = 0; t < VEC; ++t) acc[t] = ACC ? out[(size_t)row * ld_out + c + t] : 0.f;   // ACC: add onto what is there
     int j = beg;
     // 8 table rows in flight per wave
     for (; j + 8 <= end; j += 8) {
@@ -313,6 +313,22 @@ int esc_bag_fwd(const float* table, int64_t H, const int32_t* row_ptr, const int
   else
     esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
   ESC_CHECK_LAUNCH("esc_bag_fwd");
+  return ESC_OK;
+}
+
+int esc_bag_fwd_acc(const float* table, int64_t H, const int32_t* row_ptr, const int32_t* idx32,
+                    const int32_t* val32, int64_t E, float* out, int64_t ld_out, void* stream) {
+  ESC_REQUIRE(table && row_ptr && out && idx32 && val32, "esc_bag_fwd_acc: null pointer");
+  ESC_REQUIRE(H > 0 && E >= 0 && ld_out >= H && E < (1LL << 31) / 64, "esc_bag_fwd_acc: bad sizes H=%ld E=%ld ld=%ld", (long)H, (long)E, (long)ld_out);
+  if (E == 0) return ESC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (H % 4 == 0) && (ld_out % 4 == 0) && esc::aligned16(table) && esc::aligned16(out);
+  const int64_t blocks = esc::cdiv(E, 4);
+  if (vec)
+    esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_kernel<4, true>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
+  else
+    esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_kernel<1, true>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
+  ESC_CHECK_LAUNCH("esc_bag_fwd_acc");
   return ESC_OK;
 }
 

@@ -45,6 +45,80 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   }
 }
 
+
+// out[i,:] = x[i,:] + rows[graph(i),:] — the virtual-node broadcast h + vn[batch] (ogb_mol_gnn.py:739); one wave per graph
+__global__ __launch_bounds__(256) void segment_broadcast_add_kernel(const float* __restrict__ x, int64_t ld_x,
+                                                                    const float* __restrict__ rows, int64_t ld_r,
+                                                                    const int* __restrict__ seg_ptr, int G, int C,
+                                                                    float* __restrict__ out, int64_t ld_o) {
+  const int g = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+  if (g >= G) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = seg_ptr[g], end = seg_ptr[g + 1];
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(rows + (size_t)g * ld_r + c);
+    for (int r = beg; r < end; ++r) {
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x) q = *reinterpret_cast<const float4*>(x + (size_t)r * ld_x + c);
+      *reinterpret_cast<float4*>(out + (size_t)r * ld_o + c) = make_float4(q.x + v.x, q.y + v.y, q.z + v.z, q.w + v.w);
+    }
+  }
+}
+
+// counter-based uniform in [0,1): two rounds of a 64-bit mix of (seed, element index) — stateless, so the backward
+// could regenerate the mask; it is stored instead (one byte per element) to keep the two passes independent
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + i * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// y = dropout_p(x) + res:  keep with probability 1-p, scale by 1/(1-p) (torch.nn.functional.dropout); p == 0: y = x + res
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, int64_t ld_x, int64_t M, int C, float p,
+                                                          unsigned long long seed, const float* __restrict__ res, int64_t ld_r,
+                                                          float* __restrict__ y, int64_t ld_y, unsigned char* __restrict__ mask) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const int64_t r = t / C;
+  const int c = (int)(t % C);
+  float v = x[r * ld_x + c];
+  if (p > 0.f) {
+    const bool keep = uniform01(seed, (unsigned long long)t) >= p;
+    mask[t] = keep ? 1 : 0;
+    v = keep ? v / (1.f - p) : 0.f;
+  }
+  if (res) v += res[r * ld_r + c];
+  y[r * ld_y + c] = v;
+}
+
+// dx = dy * mask / (1-p)  (+ add, when given: the other branch of a residual sum)
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, int64_t ld_dy, int64_t M, int C, float p,
+                                                          const unsigned char* __restrict__ mask, const float* __restrict__ add,
+                                                          int64_t ld_a, float* __restrict__ dx, int64_t ld_dx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const int64_t r = t / C;
+  const int c = (int)(t % C);
+  float v = dy[r * ld_dy + c];
+  if (p > 0.f) v = mask[t] ? v / (1.f - p) : 0.f;
+  if (add) v += add[r * ld_a + c];
+  dx[r * ld_dx + c] = v;
+}
+
+// gather many small tables into one [total_rows, C] buffer (the sum-of-embeddings encoders look rows up in ONE table),
+// or scatter the gradient of that buffer back to the tables' own gradient slots
+__global__ __launch_bounds__(256) void table_pack_kernel(esc_table_list tl, int C, float* __restrict__ cat, int unpack) {
+  int row = blockIdx.x, j = 0;
+  while (j < tl.count && row >= tl.rows[j]) { row -= tl.rows[j]; ++j; }
+  if (j >= tl.count) return;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    if (unpack) tl.dw[j][(size_t)row * C + c] = cat[(size_t)blockIdx.x * C + c];
+    else        cat[(size_t)blockIdx.x * C + c] = tl.w[j][(size_t)row * C + c];
+  }
+}
+
 }  // namespace esc
 
 using namespace esc;
@@ -72,6 +146,57 @@ int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, i
   esc::launch(ESC_K_BAG_BWD, embed_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, g, ld_g, idx, M, C, CW, dtable);
   ESC_CHECK_LAUNCH("esc_embed_bwd");
   return ESC_OK;
+}
+
+int esc_segment_broadcast_add(const float* x, int64_t ld_x, const float* rows, int64_t ld_rows, const int32_t* seg_ptr,
+                              int64_t G, int64_t C, float* out, int64_t ld_out, void* stream) {
+  ESC_REQUIRE(rows && seg_ptr && out, "esc_segment_broadcast_add: null pointer");
+  ESC_REQUIRE(G > 0 && C > 0 && C % 4 == 0 && ld_rows % 4 == 0 && ld_out % 4 == 0 && (!x || ld_x % 4 == 0) && ld_out >= C,
+              "esc_segment_broadcast_add: C and the leading dimensions must be multiples of 4");
+  ESC_REQUIRE(aligned16(rows) && aligned16(out) && (!x || aligned16(x)), "esc_segment_broadcast_add: pointers must be 16-byte aligned");
+  esc::launch(-1, segment_broadcast_add_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, rows, ld_rows,
+              seg_ptr, (int)G, (int)C, out, ld_out);
+  ESC_CHECK_LAUNCH("esc_segment_broadcast_add");
+  return ESC_OK;
+}
+
+int esc_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int64_t C, float p, uint64_t seed, const float* res, int64_t ld_res,
+                    float* y, int64_t ld_y, uint8_t* mask, void* stream) {
+  ESC_REQUIRE(x && y && (p <= 0.f || mask), "esc_dropout_fwd: null pointer");
+  ESC_REQUIRE(M >= 0 && C > 0 && C < (1LL << 31) && p >= 0.f && p < 1.f, "esc_dropout_fwd: bad arguments (p=%g)", (double)p);
+  if (M == 0) return ESC_OK;
+  esc::launch(-1, dropout_fwd_kernel, dim3((unsigned)cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, M, (int)C, p,
+              (unsigned long long)seed, res, ld_res, y, ld_y, (unsigned char*)mask);
+  ESC_CHECK_LAUNCH("esc_dropout_fwd");
+  return ESC_OK;
+}
+
+int esc_dropout_bwd(const float* dy, int64_t ld_dy, int64_t M, int64_t C, float p, const uint8_t* mask, const float* add,
+                    int64_t ld_add, float* dx, int64_t ld_dx, void* stream) {
+  ESC_REQUIRE(dy && dx && (p <= 0.f || mask), "esc_dropout_bwd: null pointer");
+  ESC_REQUIRE(M >= 0 && C > 0 && C < (1LL << 31) && p >= 0.f && p < 1.f, "esc_dropout_bwd: bad arguments (p=%g)", (double)p);
+  if (M == 0) return ESC_OK;
+  esc::launch(-1, dropout_bwd_kernel, dim3((unsigned)cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, M, (int)C, p,
+              (const unsigned char*)mask, add, ld_add, dx, ld_dx);
+  ESC_CHECK_LAUNCH("esc_dropout_bwd");
+  return ESC_OK;
+}
+
+static int table_pack(const esc_table_list* tl, int64_t C, float* cat, int unpack, void* stream) {
+  ESC_REQUIRE(tl && cat && tl->count >= 0 && tl->count <= ESC_MAX_TABLES && C > 0, "esc_table_pack: bad table list");
+  int64_t total = 0;
+  for (int j = 0; j < tl->count; ++j) {
+    ESC_REQUIRE(tl->rows[j] > 0 && tl->w[j] && (!unpack || tl->dw[j]), "esc_table_pack: table %d is incomplete", j);
+    total += tl->rows[j];
+  }
+  if (total == 0) return ESC_OK;
+  esc::launch(-1, table_pack_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, *tl, (int)C, cat, unpack);
+  ESC_CHECK_LAUNCH("esc_table_pack");
+  return ESC_OK;
+}
+int esc_table_pack(const esc_table_list* tl, int64_t C, float* cat, void* stream) { return table_pack(tl, C, cat, 0, stream); }
+int esc_table_unpack_grad(const esc_table_list* tl, int64_t C, const float* dcat, void* stream) {
+  return table_pack(tl, C, const_cast<float*>(dcat), 1, stream);
 }
 
 }  // extern "C"

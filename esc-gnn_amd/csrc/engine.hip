@@ -290,8 +290,8 @@ static int bn_sync_forward(const Ctx& c, int64_t M, const esc_bn_t& bn, const Bn
 }
 // BatchNorm(+ReLU) backward; d(gamma), d(beta) stay this rank's sums (the gradient all-reduce adds them up)
 static int bn_backward(const Ctx& c, const float* X, int64_t ldx, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
-                       int64_t M, const BnWs& w, const esc_bn_t& bn, float* dX, int64_t lddx, float* scratch) {
-  const int64_t C = c.y.H;
+                       int64_t M, const BnWs& w, const esc_bn_t& bn, float* dX, int64_t lddx, float* scratch, int64_t width = 0) {
+  const int64_t C = width > 0 ? width : c.y.H;
   if (!sync_on(c))
     return esc_bn_bwd(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, c.act, dX, lddx, bn.dgamma, bn.dbeta,
                       scratch, c.s);
@@ -307,7 +307,7 @@ static int bn_backward(const Ctx& c, const float* X, int64_t ldx, const float* Y
 static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linear_t& lin, const float* sc, const float* sh,
                      int64_t M, float* Y, const esc_bn_t& bn, const BnWs& w) {
   const LdsFloorGuard cap(c.on_edge_stream && g_cap_forward);
-  const int64_t H = c.y.H, K = lin.in_dim;
+  const int64_t H = lin.out_dim, K = lin.in_dim;          // (the BatchNorm is as wide as the Linear's output)
   const bool sync = sync_on(c);     // statistics over all ranks: local ones first (no running update, no coefficients), then the exchange
   const bool fused = c.train && g_gemm_stats && H > 32 && c.jobs != nullptr;   // main chain only (col_stats is shared scratch)
   if (fused && g_fuse_finalize && M > 1 && !sync) {    // statistics AND their merge ride on the GEMM launch
@@ -331,8 +331,8 @@ static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linea
   return esc_bn_eval_coef(bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, H, w.scale, w.shift, c.s);
 }
 
-static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const esc_bn_t& bn, const BnWs& w) {
-  const int64_t C = c.y.H;
+static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const esc_bn_t& bn, const BnWs& w, int64_t width = 0) {
+  const int64_t C = width > 0 ? width : c.y.H;
   if (c.train) {
     const bool sync = sync_on(c);
     ESC_TRY(esc_bn_stats(X, ld, M, C, bn.eps, bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
@@ -749,6 +749,254 @@ static ZincCtx make_zinc(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, floa
   return z;
 }
 
+// =====================================================================================================================
+// OGB molecule variant (ogb_mol_gnn.py: GNN(gnn_type='gin_eff'), virtual node, JK last): one stream, ReLU,
+// materialised activations, dropout with its own counter-based stream.
+// =====================================================================================================================
+struct OgbLayer {
+  float *hin, *e, *agg, *Y0, *A1, *hc, *hb;       // hin = h + vn[batch]; Y0/A1 [N,2H]; hc pre-BN; hb after BN(+ReLU)
+  BnWs b0, bn;
+  unsigned char* mask_h;
+  float *tmp, *V0, *VA, *V1, *VB, *vn;             // virtual-node update (rows G); vn = the embedding ENTERING layer l
+  BnWs vb0, vb1;
+  unsigned char* mask_v;
+  float* d_e;
+};
+struct OgbLayout {
+  int64_t N, E, Z, G, H, L, T;
+  float *Tcat, *dTcat, *h0, *hL;
+  float *Zb, *Zd, *A0, *Yz, *Yzd, *Zemb; BnWs zb0, zb1;
+  unsigned char *mask_z0, *mask_z1;
+  OgbLayer l[ESC_MAX_LAYERS];
+  float *h[ESC_MAX_LAYERS + 1];
+  float *pooled, *logits, *dlogits;
+  // backward
+  float *dpooled, *dHa, *dHb, *dT, *dA1, *dagg, *dZemb, *dYz, *dA0, *dvn_a, *dvn_b, *dG1, *dG2, *dtmp, *poolG;
+  float *deps_part, *bag_scratch, *emb_scratch, *slabs, *bn_scratch, *col_stats;
+  int64_t total;
+};
+
+static unsigned char* take_bytes(Arena& a, int64_t n) { return reinterpret_cast<unsigned char*>(a.take((n + 3) / 4)); }
+
+static OgbLayout plan_layout_ogb(const esc_ogb_gnn_t* m, int64_t N, int64_t E, int64_t Z, int64_t G, int64_t atom_entries,
+                                 int64_t bond_entries, float* base, bool train) {
+  OgbLayout y{};
+  Arena a{base, 0};
+  const int64_t H = m->hidden, L = m->num_layers, T = m->num_tasks, H2 = 2 * H;
+  const bool drop = train && m->drop_ratio > 0.f;
+  y.N = N; y.E = E; y.Z = Z; y.G = G; y.H = H; y.L = L; y.T = T;
+  const int64_t rows_total = m->atom_rows + L * m->bond_rows;
+  y.Tcat = a.take(rows_total * H);
+  y.h0 = a.take(N * H); y.h[0] = y.h0;
+  y.Zb = a.take(E * H); y.Zd = drop ? a.take(E * H) : y.Zb; y.A0 = a.take(E * H);
+  y.Yz = a.take(E * H); y.Yzd = drop ? a.take(E * H) : y.Yz; y.Zemb = a.take(E * H);
+  y.zb0 = take_bn(a, H); y.zb1 = take_bn(a, H);
+  if (drop) { y.mask_z0 = take_bytes(a, E * H); y.mask_z1 = take_bytes(a, E * H); }
+  for (int l = 0; l < L; ++l) {
+    OgbLayer& q = y.l[l];
+    q.vn = a.take(G * H);
+    q.hin = a.take(N * H); q.e = a.take(E * H); q.agg = a.take(N * H);
+    q.Y0 = a.take(N * H2); q.A1 = a.take(N * H2); q.hc = a.take(N * H); q.hb = a.take(N * H);
+    q.b0 = take_bn(a, H2); q.bn = take_bn(a, H);
+    y.h[l + 1] = a.take(N * H);
+    if (drop) q.mask_h = take_bytes(a, N * H);
+    if (l < L - 1) {
+      q.tmp = a.take(G * H); q.V0 = a.take(G * H2); q.VA = a.take(G * H2); q.V1 = a.take(G * H); q.VB = a.take(G * H);
+      q.vb0 = take_bn(a, H2); q.vb1 = take_bn(a, H);
+      if (drop) q.mask_v = take_bytes(a, G * H);
+    }
+  }
+  y.hL = y.h[L];
+  y.pooled = a.take(G * H); y.logits = a.take(G * T); y.dlogits = a.take(G * T);
+  y.bn_scratch = a.take(esc_bn_scratch(H2));
+  y.col_stats = a.take(2 * ((E > N ? E : N) / 32 + 1) * H2);
+  if (train) {
+    y.dTcat = a.take(rows_total * H);
+    y.dpooled = a.take(G * H); y.dHa = a.take(N * H); y.dHb = a.take(N * H); y.dT = a.take(N * H);
+    y.dA1 = a.take(N * H2); y.dagg = a.take(N * H);
+    y.dZemb = a.take(E * H); y.dYz = a.take(E * H); y.dA0 = a.take(E * H);
+    y.dvn_a = a.take(G * H); y.dvn_b = a.take(G * H); y.dG1 = a.take(G * H2); y.dG2 = a.take(G * H); y.dtmp = a.take(G * H);
+    y.poolG = a.take(G * H);
+    for (int l = 0; l < L; ++l) y.l[l].d_e = a.take(E * H);
+    y.deps_part = a.take(N * (L > 0 ? L : 1));
+    y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
+    const int64_t ent = atom_entries > bond_entries ? atom_entries : bond_entries;
+    y.emb_scratch = a.take(esc_bag_bwd_scratch(ent, H));
+    int64_t sl = esc_linear_bwd_weight_scratch(E, H, H) + 64;                                   // zlin
+    for (int l = 0; l < L; ++l) {
+      sl += esc_linear_bwd_weight_scratch(E, H, H) + esc_linear_bwd_weight_scratch(N, H2, H) +
+            esc_linear_bwd_weight_scratch(N, H, H2) + 3 * 64;                                     // pos, lin0, lin1
+      if (l < L - 1) sl += esc_linear_bwd_weight_scratch(G, H2, H) + esc_linear_bwd_weight_scratch(G, H, H2) + 2 * 64;
+    }
+    sl += esc_linear_bwd_weight_scratch(G, T, H) + 64;                                          // head
+    y.slabs = a.take(sl);
+  }
+  y.total = a.off;
+  return y;
+}
+
+struct OgbCtx {
+  const esc_ogb_gnn_t* m;
+  const esc_ogb_batch_t* b;
+  OgbLayout o;
+  Ctx c;                // helpers' view (H, col_stats, bn_scratch, slabs, stream, jobs); act = ReLU
+  float p;              // dropout probability of this call (0 in eval mode)
+};
+
+static uint64_t drop_seed(const OgbCtx& z, int which) { return z.b->seed * 0x2545F4914F6CDD1Dull + (uint64_t)(which + 1) * 0xD1342543DE82EF95ull; }
+
+static int forward_ogb(const OgbCtx& z) {
+  const esc_ogb_gnn_t* m = z.m;
+  const esc_ogb_batch_t* b = z.b;
+  const OgbLayout& y = z.o;
+  const Ctx& c = z.c;
+  const int64_t N = y.N, E = y.E, H = y.H, L = y.L, G = y.G, T = y.T, H2 = 2 * H;
+  const float p = z.p;
+  // encoders' tables in one buffer; h0 = AtomEncoder(x) (:264-282); vn_0 = virtualnode_embedding(0) per graph (:701)
+  ESC_TRY(esc_table_pack(&m->tables, H, y.Tcat, c.s));
+  ESC_TRY(esc_bag_fwd(y.Tcat, H, b->atoms.row_ptr, b->atoms.idx, b->atoms.ones, N, y.h0, H, c.s));
+  ESC_TRY(esc_embed_fwd(m->vn_w, 1, H, b->zero_idx, G, y.l[0].vn, H, nullptr, c.s));
+  // z_emb = z_embedding(ESC bag): Dropout BN ReLU Linear Dropout BN ReLU (:638-645)
+  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, c.s));
+  if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, c.s));
+  if (p > 0.f) ESC_TRY(esc_dropout_fwd(y.Zb, H, E, H, p, drop_seed(z, 0), nullptr, 0, y.Zd, H, y.mask_z0, c.s));
+  ESC_TRY(bn_coeffs(c, y.Zd, H, E, m->zbn0, y.zb0));
+  ESC_TRY(esc_affine_act(y.Zd, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, c.s));
+  if (p > 0.f) {
+    ESC_TRY(esc_linear_fwd(y.A0, H, m->zlin.w, H, m->zlin.b, nullptr, nullptr, E, H, H, y.Yz, H, nullptr, c.s));
+    ESC_TRY(esc_dropout_fwd(y.Yz, H, E, H, p, drop_seed(z, 1), nullptr, 0, y.Yzd, H, y.mask_z1, c.s));
+    ESC_TRY(bn_coeffs(c, y.Yzd, H, E, m->zbn1, y.zb1));
+  } else {
+    ESC_TRY(linear_bn(c, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
+  }
+  ESC_TRY(esc_affine_act(y.Yzd, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, c.s));
+  for (int l = 0; l < (int)L; ++l) {
+    const esc_ogb_layer_t& q = m->layer[l];
+    const OgbLayer& w = y.l[l];
+    ESC_TRY(esc_segment_broadcast_add(y.h[l], H, w.vn, H, b->graph_ptr, G, H, w.hin, H, c.s));                    // :739
+    // edge term = BondEncoder(edge_attr) + edge_encoder_pos(z_emb) (:352)
+    ESC_TRY(esc_linear_fwd(y.Zemb, H, q.pos.w, H, q.pos.b, nullptr, nullptr, E, H, H, w.e, H, nullptr, c.s));
+    ESC_TRY(esc_bag_fwd_acc(y.Tcat + q.bond_row0 * H, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, w.e, H, c.s));
+    ESC_TRY(esc_gine_aggregate_fwd(w.hin, H, w.e, H, b->in_ptr, b->in_edge, b->in_src, q.eps, N, H, w.agg, H, c.s));
+    ESC_TRY(linear_bn(c, w.agg, H, q.lin0, nullptr, nullptr, N, w.Y0, q.bn0, w.b0));
+    ESC_TRY(esc_affine_act(w.Y0, H2, N, H2, w.b0.scale, w.b0.shift, 1, w.A1, H2, c.s));
+    ESC_TRY(linear_bn(c, w.A1, H2, q.lin1, nullptr, nullptr, N, w.hc, q.bn, w.bn));                                // + batch_norms[l] statistics
+    ESC_TRY(esc_affine_act(w.hc, H, N, H, w.bn.scale, w.bn.shift, l == (int)L - 1 ? 0 : 1, w.hb, H, c.s));         // :744-749
+    ESC_TRY(esc_dropout_fwd(w.hb, H, N, H, p, drop_seed(z, 2 + 2 * l), m->residual ? w.hin : nullptr, H, y.h[l + 1], H, w.mask_h, c.s));
+    if (l < (int)L - 1) {                                                                                            // :757-783
+      ESC_TRY(esc_segment_pool_fwd(w.hin, H, b->graph_ptr, G, H, 0, w.tmp, H, c.s));
+      ESC_TRY(esc_dropout_fwd(w.tmp, H, G, H, 0.f, 0, w.vn, H, w.tmp, H, nullptr, c.s));                            // + vn
+      ESC_TRY(linear_bn(c, w.tmp, H, q.vlin0, nullptr, nullptr, G, w.V0, q.vbn0, w.vb0));
+      ESC_TRY(esc_affine_act(w.V0, H2, G, H2, w.vb0.scale, w.vb0.shift, 1, w.VA, H2, c.s));
+      ESC_TRY(linear_bn(c, w.VA, H2, q.vlin1, nullptr, nullptr, G, w.V1, q.vbn1, w.vb1));
+      ESC_TRY(esc_affine_act(w.V1, H, G, H, w.vb1.scale, w.vb1.shift, 1, w.VB, H, c.s));
+      ESC_TRY(esc_dropout_fwd(w.VB, H, G, H, p, drop_seed(z, 3 + 2 * l), m->residual ? w.vn : nullptr, H, y.l[l + 1].vn, H, w.mask_v, c.s));
+    }
+  }
+  ESC_TRY(esc_segment_pool_fwd(y.hL, H, b->graph_ptr, G, H, m->mean_pool, y.pooled, H, c.s));
+  return esc_linear_fwd(y.pooled, H, m->head.w, H, m->head.b, nullptr, nullptr, G, T, H, y.logits, T, nullptr, c.s);
+}
+
+static int backward_ogb(const OgbCtx& z) {
+  const esc_ogb_gnn_t* m = z.m;
+  const esc_ogb_batch_t* b = z.b;
+  const OgbLayout& y = z.o;
+  const Ctx& c = z.c;
+  Ctx c0 = c; c0.act = 0;                        // the last layer's batch_norm has no ReLU
+  const int64_t N = y.N, E = y.E, H = y.H, L = y.L, G = y.G, T = y.T, H2 = 2 * H;
+  const float p = z.p;
+  ESC_TRY(linear_backward(c, y.dlogits, T, y.pooled, H, nullptr, nullptr, m->head, G, y.dpooled, H, 0));
+  float* dH = y.dHa;                             // d h_{l+1}
+  float* dHin = y.dHb;                           // d (h_l + vn_l[batch]) under construction
+  ESC_TRY(esc_segment_pool_bwd(y.dpooled, H, b->graph_ptr, G, H, m->mean_pool, dH, H, c.s));
+  float* dvn_next = nullptr;                     // d vn_{l+1}
+  float* dvn_cur = y.dvn_a;
+  std::vector<esc_sum_job> eps_jobs;
+  for (int l = (int)L - 1; l >= 0; --l) {
+    const esc_ogb_layer_t& q = m->layer[l];
+    const OgbLayer& w = y.l[l];
+    const bool last = l == (int)L - 1;
+    // h_{l+1} = dropout(hb) (+ hin)
+    const float* dhb = dH;
+    if (p > 0.f) { ESC_TRY(esc_dropout_bwd(dH, H, N, H, p, w.mask_h, nullptr, 0, y.dT, H, c.s)); dhb = y.dT; }
+    ESC_TRY(bn_backward(last ? c0 : c, w.hc, H, nullptr, 0, dhb, H, N, w.bn, q.bn, y.dT, H, y.bn_scratch));
+    ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
+    ESC_TRY(bn_backward(c, w.Y0, H2, w.A1, H2, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));
+    ESC_TRY(linear_backward(c, y.dA1, H2, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0));
+    // virtual-node update of this layer: vn_{l+1} = dropout(mlp(add_pool(hin) + vn_l)) (+ vn_l)
+    bool have_dhin = false;
+    if (!last) {
+      const float* dVB = dvn_next;
+      if (p > 0.f) { ESC_TRY(esc_dropout_bwd(dvn_next, H, G, H, p, w.mask_v, nullptr, 0, y.dG2, H, c.s)); dVB = y.dG2; }
+      ESC_TRY(bn_backward(c, w.V1, H, w.VB, H, dVB, H, G, w.vb1, q.vbn1, y.dG2, H, y.bn_scratch));
+      ESC_TRY(linear_backward(c, y.dG2, H, w.VA, H2, nullptr, nullptr, q.vlin1, G, y.dG1, H2, 0));
+      ESC_TRY(bn_backward(c, w.V0, H2, w.VA, H2, y.dG1, H2, G, w.vb0, q.vbn0, y.dG1, H2, y.bn_scratch, H2));
+      ESC_TRY(linear_backward(c, y.dG1, H2, w.tmp, H, nullptr, nullptr, q.vlin0, G, y.dtmp, H, 0));
+      // d vn_l = d tmp (+ d vn_{l+1} through the residual); d hin = broadcast(d tmp) (+ d h_{l+1} through the residual)
+      ESC_TRY(esc_dropout_bwd(y.dtmp, H, G, H, 0.f, nullptr, m->residual ? dvn_next : nullptr, H, dvn_cur, H, c.s));
+      ESC_TRY(esc_segment_broadcast_add(m->residual ? dH : nullptr, H, y.dtmp, H, b->graph_ptr, G, H, dHin, H, c.s));
+      have_dhin = true;
+    } else if (m->residual) {
+      float* t = dH; dH = dHin; dHin = t;          // d hin starts as d h_{l+1}: accumulate into that buffer
+      have_dhin = true;
+    }
+    ESC_TRY(esc_gine_aggregate_bwd(w.hin, H, w.e, H, y.dagg, H, b->out_ptr, b->out_edge, b->out_dst, q.eps, N, H, w.d_e, H,
+                                   dHin, H, have_dhin ? 1 : 0, y.deps_part + (int64_t)l * N, c.s));
+    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, q.deps});
+    // edge term: bond tables and edge_encoder_pos
+    ESC_TRY(esc_bag_bwd_table(w.d_e, H, H, b->bonds.col_ptr, b->bonds.c_row, b->bonds.ones, b->bonds.c_col, b->bonds.n_entries,
+                              m->bond_rows, y.dTcat + q.bond_row0 * H, y.emb_scratch, c.s));
+    ESC_TRY(linear_backward(c, w.d_e, H, y.Zemb, H, nullptr, nullptr, q.pos, E, y.dZemb, H, last ? 0 : 1));
+    // d hin_l is complete: d h_l = d hin_l, d vn_l += add_pool(d hin_l)
+    ESC_TRY(esc_segment_pool_fwd(dHin, H, b->graph_ptr, G, H, 0, y.poolG, H, c.s));
+    ESC_TRY(esc_dropout_bwd(y.poolG, H, G, H, 0.f, nullptr, last ? nullptr : dvn_cur, H, dvn_cur, H, c.s));
+    dvn_next = dvn_cur;
+    dvn_cur = dvn_cur == y.dvn_a ? y.dvn_b : y.dvn_a;
+    { float* t = dH; dH = dHin; dHin = t; }       // dH = d h_l
+  }
+  // encoders
+  ESC_TRY(esc_bag_bwd_table(dH, H, H, b->atoms.col_ptr, b->atoms.c_row, b->atoms.ones, b->atoms.c_col, b->atoms.n_entries,
+                            m->atom_rows, y.dTcat, y.emb_scratch, c.s));
+  ESC_TRY(esc_embed_bwd(dvn_next, H, b->zero_idx, G, 1, H, m->vn_dw, c.s));
+  ESC_TRY(esc_table_unpack_grad(&m->tables, H, y.dTcat, c.s));
+  // z_embedding + bag
+  ESC_TRY(bn_backward(c, y.Yzd, H, y.Zemb, H, y.dZemb, H, E, y.zb1, m->zbn1, y.dYz, H, y.bn_scratch));
+  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dYz, H, E, H, p, y.mask_z1, nullptr, 0, y.dYz, H, c.s));
+  ESC_TRY(linear_backward(c, y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dA0, H, 0));
+  ESC_TRY(bn_backward(c, y.Zd, H, y.A0, H, y.dA0, H, E, y.zb0, m->zbn0, y.dA0, H, y.bn_scratch));
+  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dA0, H, E, H, p, y.mask_z0, nullptr, 0, y.dA0, H, c.s));
+  ESC_TRY(esc_bag_bwd_table_rows(y.dA0, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
+                                 m->dz_table, y.bag_scratch, c.s));
+  if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
+  if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
+  return ESC_OK;
+}
+
+static int check_ogb(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, const float* ws, bool train, bool need_y) {
+  ESC_REQUIRE(m && b && ws, "esc_ogb: null pointer");
+  ESC_REQUIRE(m->num_layers >= 1 && m->num_layers <= ESC_MAX_LAYERS, "esc_ogb: %ld layers unsupported", (long)m->num_layers);
+  ESC_REQUIRE(m->hidden > 0 && m->hidden % 4 == 0 && m->num_tasks >= 1, "esc_ogb: hidden must be a multiple of 4");
+  ESC_REQUIRE(m->drop_ratio >= 0.f && m->drop_ratio < 1.f, "esc_ogb: drop_ratio %g outside [0,1)", (double)m->drop_ratio);
+  ESC_REQUIRE(m->tables.count > 0 && m->tables.count <= ESC_MAX_TABLES && m->atom_rows > 0 && m->bond_rows > 0 && m->vn_w,
+              "esc_ogb: encoder tables missing");
+  ESC_REQUIRE(b->N >= 2 && b->E >= 2 && b->Z >= 0 && b->G >= 2, "esc_ogb: batch needs >= 2 nodes, edges and graphs (BatchNorm statistics)");
+  ESC_REQUIRE(b->graph_ptr && b->zero_idx && b->in_ptr && b->row_ptr && b->atoms.row_ptr && b->atoms.idx && b->atoms.ones &&
+              b->bonds.row_ptr && b->bonds.idx && b->bonds.ones, "esc_ogb: null batch arrays");
+  ESC_REQUIRE(!train || ((b->y || !need_y) && b->out_ptr && b->col_ptr && b->atoms.col_ptr && b->atoms.c_row && b->atoms.c_col &&
+                         b->bonds.col_ptr && b->bonds.c_row && b->bonds.c_col && m->vn_dw), "esc_ogb: null training arrays");
+  ESC_REQUIRE(aligned16(ws), "esc_ogb: workspace must be 16-byte aligned");
+  return ESC_OK;
+}
+
+static OgbCtx make_ogb(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* ws, void* stream, bool train) {
+  OgbCtx z{m, b, plan_layout_ogb(m, b->N, b->E, b->Z, b->G, b->atoms.n_entries, b->bonds.n_entries, ws, train),
+           Ctx{nullptr, nullptr, Layout{}, stream, train}, train ? m->drop_ratio : 0.f};
+  z.c.y.H = m->hidden; z.c.y.N = b->N; z.c.y.E = b->E;
+  z.c.y.col_stats = z.o.col_stats; z.c.y.bn_scratch = z.o.bn_scratch; z.c.y.slabs = z.o.slabs;
+  z.c.act = 1;
+  return z;
+}
+
 static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* ws, bool train, bool need_y = true) {
   ESC_REQUIRE(m && b && ws, "esc_engine: null pointer");
   ESC_REQUIRE(m->num_layers >= 1 && m->num_layers <= ESC_MAX_LAYERS, "esc_engine: %ld layers unsupported", (long)m->num_layers);
@@ -985,6 +1233,67 @@ int esc_zinc_predict(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* w
   ZincCtx z = make_zinc(m, b, workspace, stream, false);
   ESC_TRY(forward_zinc(z));
   return copy_floats(pred, z.c.y.pred, b->G, stream, "esc_zinc_predict");
+}
+
+// ---- OGB molecule variant ------------------------------------------------------------------------------------------------
+int64_t esc_ogb_workspace_floats(const esc_ogb_gnn_t* m, int64_t N, int64_t E, int64_t Z, int64_t G, int64_t atom_entries,
+                                 int64_t bond_entries) {
+  if (!m || N < 0 || E < 0 || Z < 0 || G < 0 || atom_entries < 0 || bond_entries < 0) return -1;
+  return plan_layout_ogb(m, N, E, Z, G, atom_entries, bond_entries, nullptr, true).total + 64;
+}
+
+static void ogb_jobs(OgbCtx& z, std::vector<esc_reduce_job>& jobs, float*& cursor) {
+  jobs.reserve(ESC_MAX_REDUCE_JOBS);
+  cursor = z.o.slabs;
+  if (5 * z.m->num_layers + 2 <= ESC_MAX_REDUCE_JOBS) { z.c.jobs = &jobs; z.c.slab_cursor = &cursor; }
+}
+
+int esc_ogb_train_step(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, int64_t loss_denom, float* loss,
+                       float* logits, void* stream) {
+  int rc = check_ogb(m, b, workspace, true, true);
+  if (rc) return rc;
+  ESC_REQUIRE(loss, "esc_ogb_train_step: null loss pointer");
+  OgbCtx z = make_ogb(m, b, workspace, stream, true);
+  std::vector<esc_reduce_job> jobs;
+  float* cursor = nullptr;
+  ogb_jobs(z, jobs, cursor);
+  ESC_TRY(forward_ogb(z));
+  ESC_TRY(esc_bce_logits_loss(z.o.logits, b->y, b->G * m->num_tasks, loss_denom, loss, z.o.dlogits, stream));
+  if (logits) ESC_TRY(copy_floats(logits, z.o.logits, b->G * m->num_tasks, stream, "esc_ogb_train_step"));
+  return backward_ogb(z);
+}
+
+int esc_ogb_forward_train(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, float* logits, void* stream) {
+  int rc = check_ogb(m, b, workspace, true, false);
+  if (rc) return rc;
+  ESC_REQUIRE(logits, "esc_ogb_forward_train: null output");
+  OgbCtx z = make_ogb(m, b, workspace, stream, true);
+  std::vector<esc_reduce_job> jobs;
+  float* cursor = z.o.slabs;
+  z.c.jobs = &jobs; z.c.slab_cursor = &cursor;
+  ESC_TRY(forward_ogb(z));
+  return copy_floats(logits, z.o.logits, b->G * m->num_tasks, stream, "esc_ogb_forward_train");
+}
+
+int esc_ogb_backward(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, const float* dlogits, void* stream) {
+  int rc = check_ogb(m, b, workspace, true, false);
+  if (rc) return rc;
+  ESC_REQUIRE(dlogits, "esc_ogb_backward: null gradient");
+  OgbCtx z = make_ogb(m, b, workspace, stream, true);
+  std::vector<esc_reduce_job> jobs;
+  float* cursor = nullptr;
+  ogb_jobs(z, jobs, cursor);
+  ESC_TRY(copy_floats(z.o.dlogits, dlogits, b->G * m->num_tasks, stream, "esc_ogb_backward"));
+  return backward_ogb(z);
+}
+
+int esc_ogb_predict(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, float* logits, void* stream) {
+  int rc = check_ogb(m, b, workspace, false, false);
+  if (rc) return rc;
+  ESC_REQUIRE(logits, "esc_ogb_predict: null output");
+  OgbCtx z = make_ogb(m, b, workspace, stream, false);
+  ESC_TRY(forward_ogb(z));
+  return copy_floats(logits, z.o.logits, b->G * m->num_tasks, stream, "esc_ogb_predict");
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@ path for the same module: it reads the module's parameters, writes the same `.gr
 checkpoints, `optimizer.step()` and the data-parallel all-reduce are unchanged.
 """
 import ctypes
-from ctypes import c_float, c_int64, c_void_p
+from ctypes import c_float, c_int32, c_int64, c_uint64, c_void_p
 
 import torch
 
@@ -515,3 +515,242 @@ def zinc_engine_forward(model, data):
         c = _ZincNodeCache(model)
         model.__dict__["_esc_node_cache"] = c
     return _ZincEngineNode.apply(model, data, c, *c.params)
+
+
+# ---- OGB molecule variant (ogb_mol_gnn.GNN(gnn_type="gin_eff"); csrc/engine.hip esc_ogb_*) -----------------------------
+MAX_TABLES = 64
+
+
+class _TableList(ctypes.Structure):
+    _fields_ = [("count", c_int32), ("rows", c_int32 * MAX_TABLES), ("w", c_void_p * MAX_TABLES), ("dw", c_void_p * MAX_TABLES)]
+
+
+class _OgbLayer(ctypes.Structure):
+    _fields_ = [("eps", c_void_p), ("deps", c_void_p), ("pos", _Linear), ("lin0", _Linear), ("bn0", _BN), ("lin1", _Linear),
+                ("bn", _BN), ("vlin0", _Linear), ("vbn0", _BN), ("vlin1", _Linear), ("vbn1", _BN), ("bond_row0", c_int64)]
+
+
+class _OgbModel(ctypes.Structure):
+    _fields_ = [("num_layers", c_int64), ("hidden", c_int64), ("z_rows", c_int64), ("num_tasks", c_int64),
+                ("residual", c_int32), ("mean_pool", c_int32), ("drop_ratio", c_float), ("pad_", c_int32),
+                ("z_table", c_void_p), ("dz_table", c_void_p), ("zbn0", _BN), ("zlin", _Linear), ("zbn1", _BN),
+                ("tables", _TableList), ("atom_rows", c_int64), ("bond_rows", c_int64), ("vn_w", c_void_p), ("vn_dw", c_void_p),
+                ("layer", _OgbLayer * MAX_LAYERS), ("head", _Linear)]
+
+
+class _BagPlan(ctypes.Structure):
+    _fields_ = [("n_entries", c_int64)] + [(n, c_void_p) for n in ("row_ptr", "idx", "ones", "col_ptr", "c_row", "c_col")]
+
+
+class _OgbBatch(ctypes.Structure):
+    _fields_ = ([("N", c_int64), ("E", c_int64), ("Z", c_int64), ("G", c_int64), ("atoms", _BagPlan), ("bonds", _BagPlan),
+                 ("y", c_void_p), ("graph_ptr", c_void_p), ("zero_idx", c_void_p)] +
+                [(n, c_void_p) for n in ("in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst",
+                                         "row_ptr", "bag_idx", "bag_val", "col_ptr", "col_row", "col_val", "col_col")] +
+                [("seed", c_uint64)])
+
+
+def ogb_engine_supports(m, data=None):
+    """what esc_ogb_* covers: the run_ogb_mol `--gnn gin_eff` configuration — ogbg-mol* encoders, virtual node, JK last,
+    sum / mean pooling, per-rank BatchNorm statistics; sparse ESC bag; at least two graphs per batch"""
+    from .ogb_mol_gnn import AtomEncoder, BondEncoder
+    g = m.gnn_node
+    if g.JK != "last" or not g.virtual_node or g.skip_node_encoder or m.graph_pooling not in ("sum", "mean") or _sync_groups(m):
+        return False
+    if m.graph_pred_linear.weight.device.type != "cuda" or m.emb_dim % 4 != 0 or not isinstance(g.node_encoder, AtomEncoder):
+        return False
+    if not all(isinstance(cv.edge_encoder, BondEncoder) for cv in g.convs):
+        return False
+    if data is not None:
+        if "edge_pos" in data or "pos_batch" not in data or data.edge_index.size(1) < 2 or data["edge_attr"] is None:
+            return False
+        if data.x.dim() != 2 or data.x.size(1) != 9 or data.edge_attr.dim() != 2 or data.edge_attr.size(1) != 3:
+            return False
+    return True
+
+
+def describe_ogb(m, gp=_grad_ptr):
+    """esc_ogb_gnn_t of an ogb_mol_gnn.GNN module"""
+    g = m.gnn_node
+    L = g.num_layer
+    if L > MAX_LAYERS:
+        raise ValueError("at most %d layers" % MAX_LAYERS)
+    d = _OgbModel()
+    d.num_layers, d.hidden, d.z_rows, d.num_tasks = L, m.emb_dim, g.z_initial.num_embeddings, m.num_tasks
+    d.residual, d.mean_pool, d.drop_ratio = int(bool(g.residual)), int(m.graph_pooling == "mean"), float(g.drop_ratio)
+    d.z_table, d.dz_table = g.z_initial.weight.data_ptr(), gp(g.z_initial.weight)
+    d.zbn0, d.zlin, d.zbn1 = _bn(g.z_embedding[1], gp), _lin(g.z_embedding[3], gp), _bn(g.z_embedding[5], gp)
+    tabs = list(g.node_encoder.atom_embedding_list)
+    d.atom_rows = sum(t.num_embeddings for t in tabs)
+    bond_rows = sum(t.num_embeddings for t in g.convs[0].edge_encoder.bond_embedding_list)
+    d.bond_rows = bond_rows
+    for l, cv in enumerate(g.convs):
+        tabs += list(cv.edge_encoder.bond_embedding_list)
+    if len(tabs) > MAX_TABLES:
+        raise ValueError("too many embedding tables for the OGB engine")
+    d.tables.count = len(tabs)
+    for j, t in enumerate(tabs):
+        d.tables.rows[j], d.tables.w[j], d.tables.dw[j] = t.num_embeddings, t.weight.data_ptr(), gp(t.weight)
+    d.vn_w, d.vn_dw = g.virtualnode_embedding.weight.data_ptr(), gp(g.virtualnode_embedding.weight)
+    for l, cv in enumerate(g.convs):
+        q = _OgbLayer()
+        q.eps, q.deps = cv.eps.data_ptr(), gp(cv.eps)
+        q.pos = _lin(cv.edge_encoder_pos, gp)
+        q.lin0, q.bn0, q.lin1 = _lin(cv.mlp[0], gp), _bn(cv.mlp[1], gp), _lin(cv.mlp[3], gp)
+        q.bn = _bn(g.batch_norms[l], gp)
+        if l < L - 1:
+            v = g.mlp_virtualnode_list[l]
+            q.vlin0, q.vbn0, q.vlin1, q.vbn1 = _lin(v[0], gp), _bn(v[1], gp), _lin(v[3], gp), _bn(v[4], gp)
+        q.bond_row0 = d.atom_rows + l * bond_rows
+        d.layer[l] = q
+    d.head = _lin(m.graph_pred_linear, gp)
+    return d
+
+
+def _bag_plan(plan):
+    b = _BagPlan()
+    b.n_entries = plan["entries"]
+    b.row_ptr, b.idx, b.ones = plan["row_ptr"].data_ptr(), plan["idx32"].data_ptr(), plan["ones"].data_ptr()
+    b.col_ptr, b.c_row, b.c_col = plan["col_ptr"].data_ptr(), plan["c_row"].data_ptr(), plan["c_col"].data_ptr()
+    return b
+
+
+_zero_idx = {}
+
+
+def _ogb_batch(model, data, need_y, seed):
+    from .ogb_mol_gnn import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
+    from .ops import embed_plan
+    from .plan import graph_ptr_of
+    from .run_graphcount import Z_TABLE_ROWS
+    dev = model.graph_pred_linear.weight.device
+    if data.edge_index.device != dev:
+        data.to(dev)
+    plan = plan_of(data, Z_TABLE_ROWS)
+    gptr, G = graph_ptr_of(data, plan)
+    pa, pb = embed_plan(data.x, ATOM_FEATURE_DIMS), embed_plan(data.edge_attr, BOND_FEATURE_DIMS)
+    b = _OgbBatch()
+    b.N, b.E, b.Z, b.G = plan.num_nodes, plan.num_edges, plan.nnz, G
+    if data.x.size(0) != b.N or data.edge_attr.size(0) != b.E:
+        raise ValueError("OGB engine: expected one feature row per node and per edge")
+    b.atoms, b.bonds = _bag_plan(pa), _bag_plan(pb)
+    zero = _zero_idx.get(dev)
+    if zero is None or zero.numel() < G:
+        zero = _zero_idx[dev] = torch.zeros(max(G, 1024), dtype=torch.int64, device=dev)
+    b.graph_ptr, b.zero_idx, b.seed = gptr.data_ptr(), zero.data_ptr(), int(seed) & ((1 << 64) - 1)
+    y = None
+    if need_y:
+        y = data.y.reshape(G, -1)
+        y = y if (y.dtype == torch.float32 and y.is_contiguous()) else y.float().contiguous()
+        if y.size(1) != model.num_tasks:
+            raise ValueError("OGB engine: expected [num_graphs, num_tasks] targets")
+        b.y = y.data_ptr()
+    for f in ("in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst", "row_ptr", "bag_idx", "bag_val",
+              "col_ptr", "col_row", "col_val", "col_col"):
+        setattr(b, f, getattr(plan, f).data_ptr())
+    return b, (y, plan, gptr, pa, pb, zero)
+
+
+def ogb_engine_ready(m, data):
+    if not ogb_engine_supports(m, data):
+        return False
+    from .plan import graph_ptr_of
+    from .run_graphcount import Z_TABLE_ROWS
+    return graph_ptr_of(data, plan_of(data, Z_TABLE_ROWS))[1] >= 2
+
+
+def _drop_seed(model):
+    """dropout stream of the next step: torch's seed (torch.manual_seed makes runs repeatable) + a per-model step counter"""
+    n = model.__dict__.get("_esc_drop_step", 0)
+    model.__dict__["_esc_drop_step"] = n + 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + n) & ((1 << 64) - 1)
+
+
+class OgbStepEngine(object):
+    """Training / eval step of ogb_mol_gnn.GNN(gnn_type='gin_eff') as ONE call (esc_ogb_train_step / esc_ogb_predict)"""
+
+    def __init__(self, model):
+        if not ogb_engine_supports(model):
+            raise NotImplementedError("OgbStepEngine covers ogbg-mol* gin_eff with a virtual node, JK=last, sum/mean pooling")
+        self.model = model
+        self._ws = None
+        self._bn_counters = [m.num_batches_tracked for m in model.modules()
+                             if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
+        self.refresh()
+
+    def refresh(self):
+        self._desc = describe_ogb(self.model)
+
+    def _workspace(self, b):
+        need = nv.lib().esc_ogb_workspace_floats(ctypes.byref(self._desc), b.N, b.E, b.Z, b.G, b.atoms.n_entries, b.bonds.n_entries)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25), dtype=torch.float32, device=self.model.graph_pred_linear.weight.device)
+        return self._ws
+
+    def train_step(self, data, loss_denom=None, return_pred=False):
+        """forward + masked BCE-with-logits + backward; gradients land in the parameters' .grad (overwritten)"""
+        dev = self.model.graph_pred_linear.weight.device
+        b, keep = _ogb_batch(self.model, data, True, _drop_seed(self.model))
+        ws = self._workspace(b)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        pred = torch.empty((b.G, self.model.num_tasks), dtype=torch.float32, device=dev) if return_pred else None
+        nv.call("esc_ogb_train_step", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), int(loss_denom or 0),
+                loss.data_ptr(), nv.ptr(pred), nv.stream())
+        if self._bn_counters:
+            torch._foreach_add_(self._bn_counters, 1)
+        return (loss.view(()), pred) if return_pred else loss.view(())
+
+    @torch.no_grad()
+    def predict(self, data):
+        dev = self.model.graph_pred_linear.weight.device
+        b, keep = _ogb_batch(self.model, data, False, 0)
+        ws = self._workspace(b)
+        pred = torch.empty((b.G, self.model.num_tasks), dtype=torch.float32, device=dev)
+        nv.call("esc_ogb_predict", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+        return pred
+
+
+class _OgbNodeCache(_NodeCache):
+    def __init__(self, model):
+        self._describe, self._struct = describe_ogb, _OgbModel
+        super().__init__(model)
+
+
+class _OgbEngineNode(torch.autograd.Function):
+    """`model(batch)` of a training-mode OGB GNN as one autograd node (esc_ogb_forward_train / esc_ogb_backward)"""
+
+    @staticmethod
+    def forward(ctx, model, data, cache, *params):
+        dev = model.graph_pred_linear.weight.device
+        b, keep = _ogb_batch(model, data, False, _drop_seed(model))
+        desc = cache.descriptor(0)
+        need = nv.lib().esc_ogb_workspace_floats(ctypes.byref(desc), b.N, b.E, b.Z, b.G, b.atoms.n_entries, b.bonds.n_entries)
+        ws = torch.empty(int(need), dtype=torch.float32, device=dev)
+        pred = torch.empty((b.G, model.num_tasks), dtype=torch.float32, device=dev)
+        nv.call("esc_ogb_forward_train", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+        if cache.counters:
+            torch._foreach_add_(cache.counters, 1)
+        ctx.cache, ctx.b, ctx.keep, ctx.ws = cache, b, keep, ws
+        return pred
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dpred):
+        cache = ctx.cache
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)
+        desc = cache.descriptor(flat.data_ptr())
+        g = dpred.reshape(-1)
+        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        nv.call("esc_ogb_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+        grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
+                      for p, o in zip(cache.params, cache.offsets))
+        ctx.ws = ctx.keep = None
+        return (None, None, None) + grads
+
+
+def ogb_engine_forward(model, data):
+    c = model.__dict__.get("_esc_node_cache")
+    if c is None or not c.valid():
+        c = _OgbNodeCache(model)
+        model.__dict__["_esc_node_cache"] = c
+    return _OgbEngineNode.apply(model, data, c, *c.params)

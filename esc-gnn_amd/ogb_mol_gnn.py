@@ -166,7 +166,14 @@ class GNN(torch.nn.Module):
         else:
             raise NotImplementedError("graph_pooling %r: only sum / mean are on the ESC hot path" % graph_pooling)
         self.graph_pred_linear = Linear(emb_dim, num_tasks)
+        self.step_engine = True       # training-mode forward through the whole-step engine when the batch allows it
 
     def forward(self, data, perturb=None):
+        if self.training and torch.is_grad_enabled() and self.step_engine and perturb is None:
+            from .engine import ogb_engine_forward, ogb_engine_ready
+            if data.edge_index.device != self.graph_pred_linear.weight.device:
+                data.to(self.graph_pred_linear.weight.device)
+            if ogb_engine_ready(self, data):
+                return ogb_engine_forward(self, data)      # one autograd node (csrc/engine.hip esc_ogb_*)
         x = self.gnn_node(data, perturb=perturb)
         return self.graph_pred_linear(self.pool(x, data.batch))

@@ -435,15 +435,26 @@ class _SegmentPool(Function):
         return dx, None, None
 
 
-def segment_pool(x, batch, size=None, mean=False):
-    """`batch` must be non-decreasing (Batch.from_data_list / the device collate produce it that way)."""
-    size = int(batch.max()) + 1 if size is None else int(size)
-    counts = torch.bincount(batch, minlength=size)
-    seg_ptr = torch.zeros(size + 1, dtype=torch.int32, device=batch.device)
-    seg_ptr[1:] = torch.cumsum(counts, 0)
+def _seg_ptr(batch, size=None):
+    """int32 [G+1] segment pointers of a non-decreasing batch vector (esc_plan_csr: integer histogram + scan), built
+    once per batch tensor and cached on it"""
+    from .plan import _csr
+    cached = getattr(batch, "_esc_seg", None)
+    if cached is not None and cached[0] == (batch._version, size):
+        return cached[1]
+    n_seg = int(batch[-1].item()) + 1 if (size is None and batch.numel()) else int(size or 0)
     if batch.numel() > 1 and not bool((batch[1:] >= batch[:-1]).all()):
         raise ValueError("segment_pool: batch vector must be sorted")
-    return _SegmentPool.apply(x, seg_ptr, mean)
+    seg_ptr = _csr(batch, max(n_seg, 1), want_perm=False)[0][:n_seg + 1]
+    batch._esc_seg = ((batch._version, size), seg_ptr)
+    return seg_ptr
+
+
+def segment_pool(x, batch, size=None, mean=False):
+    """`batch` must be non-decreasing (Batch.from_data_list / the device collate produce it that way)."""
+    _dev(x)
+    _on(x.device, batch)
+    return _SegmentPool.apply(x, _seg_ptr(batch, size), mean)
 
 
 class _Embedding(Function):
@@ -473,12 +484,10 @@ class _Embedding(Function):
         (idx,) = ctx.saved_tensors
         g, ld = _rows(g.reshape(-1, ctx.H))
         n, dev = idx.numel(), g.device
-        order = torch.sort(idx, stable=True)[1]
-        col_ptr = torch.zeros(ctx.rows + 1, dtype=torch.int32, device=dev)
-        col_ptr[1:] = torch.cumsum(torch.bincount(idx, minlength=ctx.rows), 0)
-        c_row = order.to(torch.int32)
+        from .plan import _csr
+        col_ptr, c_row = _csr(idx, ctx.rows)                 # stable grouping of the positions by table row (csrc/plan.hip)
         c_val = torch.ones(n, dtype=torch.int32, device=dev)
-        c_col = idx[order].to(torch.int32)
+        c_col = idx[c_row.long()].to(torch.int32)
         dw = torch.empty((ctx.rows, ctx.H), dtype=torch.float32, device=dev)
         scratch = torch.empty(max(1, nv.lib().esc_bag_bwd_scratch(n, ctx.H)), dtype=torch.float32, device=dev)
         nv.call("esc_bag_bwd_table", nv.ptr(g), ld, ctx.H, nv.ptr(col_ptr), nv.ptr(c_row), nv.ptr(c_val), nv.ptr(c_col),
@@ -488,6 +497,33 @@ class _Embedding(Function):
 
 def embedding(weight, index):
     return _Embedding.apply(weight, index)
+
+
+def embed_plan(index, dims):
+    """bag plan of a sum-of-embeddings lookup over the concatenated tables: CSR by output row (idx32, row_ptr, ones) and
+    CSC by table row (col_ptr, c_row, c_col); depends only on the index tensor — built once (esc_plan_csr) and cached
+    on it (the bond features of a batch are looked up by every layer)."""
+    from .plan import _csr
+    cache = getattr(index, "_esc_embed", None)
+    if cache is not None and cache[0] == (dims, index._version):
+        return cache[1]
+    n, k = index.shape
+    dev = index.device
+    dims_t = torch.tensor(dims, dtype=torch.int64, device=dev)
+    if n and bool(((index < 0) | (index >= dims_t)).any()):        # one check per index tensor, not per lookup
+        raise IndexError("embedding index out of range")
+    offs = torch.zeros(k, dtype=torch.int64, device=dev)
+    offs[1:] = torch.cumsum(dims_t, 0)[:-1]
+    flat = (index + offs).reshape(-1)
+    rows = int(sum(dims))
+    col_ptr, order = _csr(flat, rows)                # stable grouping by table row (csrc/plan.hip)
+    order = order.long()
+    plan = dict(idx32=flat.to(torch.int32), row_ptr=torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev),
+                ones=torch.ones(n * k, dtype=torch.int32, device=dev), col_ptr=col_ptr,
+                c_row=torch.div(order, k, rounding_mode="floor").to(torch.int32), c_col=flat[order].to(torch.int32),
+                entries=n * k, rows=rows)
+    index._esc_embed = ((dims, index._version), plan)
+    return plan
 
 
 class _EmbeddingSum(Function):
@@ -504,24 +540,7 @@ class _EmbeddingSum(Function):
         table = table.contiguous()
         n, k = index.shape
         H, dev = table.size(1), table.device
-        cache = getattr(index, "_esc_embed", None)
-        if cache is None or cache[0] != dims:
-            dims_t = torch.tensor(dims, dtype=torch.int64, device=dev)
-            if n and bool(((index < 0) | (index >= dims_t)).any()):        # one check per index tensor, not per lookup
-                raise IndexError("embedding index out of range")
-            offs = torch.zeros(k, dtype=torch.int64, device=dev)
-            offs[1:] = torch.cumsum(dims_t, 0)[:-1]
-            flat = (index + offs).reshape(-1)
-            order = torch.sort(flat, stable=True)[1]
-            rows = int(sum(dims))
-            col_ptr = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
-            col_ptr[1:] = torch.cumsum(torch.bincount(flat, minlength=rows), 0)
-            plan = dict(idx32=flat.to(torch.int32), row_ptr=torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev),
-                        ones=torch.ones(n * k, dtype=torch.int32, device=dev), col_ptr=col_ptr,
-                        c_row=torch.div(order, k, rounding_mode="floor").to(torch.int32), c_col=flat[order].to(torch.int32))
-            cache = (dims, plan)
-            index._esc_embed = cache
-        plan = cache[1]
+        plan = embed_plan(index, dims)
         out = torch.empty((n, H), dtype=torch.float32, device=dev)
         nv.call("esc_bag_fwd", nv.ptr(table), H, nv.ptr(plan["row_ptr"]), nv.ptr(plan["idx32"]), nv.ptr(plan["ones"]), n,
                 nv.ptr(out), H, nv.stream())
@@ -615,6 +634,4 @@ class _SegmentBroadcast(Function):
 
 def segment_broadcast(rows, batch, size=None):
     size = rows.size(0) if size is None else int(size)
-    seg_ptr = torch.zeros(size + 1, dtype=torch.int32, device=batch.device)
-    seg_ptr[1:] = torch.cumsum(torch.bincount(batch, minlength=size), 0)
-    return _SegmentBroadcast.apply(rows, seg_ptr, batch.numel())
+    return _SegmentBroadcast.apply(rows, _seg_ptr(batch, size), batch.numel())

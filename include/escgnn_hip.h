@@ -403,6 +403,76 @@ int esc_embed_fwd(const float* table, int64_t rows, int64_t C, const int64_t* id
                   int32_t* bad_flag, void* stream);
 int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, int64_t rows, int64_t C, float* dtable,
                   void* stream);
+/* out[i,:] = x[i,:] (0 if x == NULL) + rows[graph(i),:]: the virtual-node broadcast h + vn[batch] (ogb_mol_gnn.py:739) */
+int esc_segment_broadcast_add(const float* x, int64_t ld_x, const float* rows, int64_t ld_rows, const int32_t* seg_ptr,
+                              int64_t G, int64_t C, float* out, int64_t ld_out, void* stream);
+/* y = F.dropout(x, p, training=True) (+ res): keep with probability 1-p and scale by 1/(1-p); the keep mask (one byte
+ * per element, [M*C]) is written for the backward.  The stream of random numbers is a counter-based hash of (seed,
+ * element index) — NOT torch's generator: masks differ from the reference's, their distribution does not.  p == 0 is
+ * y = x + res with no mask.  _bwd: dx = dy * mask / (1-p) (+ add). */
+int esc_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int64_t C, float p, uint64_t seed, const float* res, int64_t ld_res,
+                    float* y, int64_t ld_y, uint8_t* mask, void* stream);
+int esc_dropout_bwd(const float* dy, int64_t ld_dy, int64_t M, int64_t C, float p, const uint8_t* mask, const float* add,
+                    int64_t ld_add, float* dx, int64_t ld_dx, void* stream);
+/* the tables of sum-of-embeddings encoders (AtomEncoder ogb_mol_gnn.py:264-282, ogb's BondEncoder) gathered into one
+ * [sum rows, C] buffer, and the gradient of that buffer scattered back to the tables' gradient slots */
+#define ESC_MAX_TABLES 64
+typedef struct esc_table_list { int32_t count; int32_t rows[ESC_MAX_TABLES]; const float* w[ESC_MAX_TABLES]; float* dw[ESC_MAX_TABLES]; } esc_table_list;
+int esc_table_pack(const esc_table_list* tables, int64_t C, float* cat, void* stream);
+int esc_table_unpack_grad(const esc_table_list* tables, int64_t C, const float* dcat, void* stream);
+/* esc_bag_fwd that ADDS the bag sums onto what `out` already holds (edge term = Linear(z) + BondEncoder(edge_attr)) */
+int esc_bag_fwd_acc(const float* table, int64_t H, const int32_t* row_ptr, const int32_t* idx32,
+                    const int32_t* val32, int64_t E, float* out, int64_t ld_out, void* stream);
+
+/* ---- whole-step engine, OGB molecule variant: GNN(gnn_type='gin_eff') of ogb_mol_gnn.py (BASELINE config 5) ----------
+ * AtomEncoder (:264-282) -> per layer h + vn[batch] (:739), GINConv_eff (:346-358: edge term = BondEncoder(edge_attr) +
+ * edge_encoder_pos(z_emb), mlp = Linear(H,2H) BN ReLU Linear(2H,H)), batch_norms[l] (+ReLU except last), dropout,
+ * residual (:744-752), virtual-node update add_pool(h)+vn -> MLP -> dropout (:757-783); JK = last; sum / mean graph
+ * pooling + graph_pred_linear (:66-261); BCE-with-logits over the labeled targets (run_ogb_mol.py:65-72).
+ * z_embedding = Dropout BN ReLU Linear Dropout BN ReLU (:638-645).  Dropout uses esc_dropout_fwd's own random stream.
+ * One stream; gradients are WRITTEN into the d* slots; needs >= 2 graphs. */
+typedef struct esc_ogb_layer_t {
+  const float* eps; float* deps;
+  esc_linear_t pos;                                        /* convs[l].edge_encoder_pos */
+  esc_linear_t lin0; esc_bn_t bn0; esc_linear_t lin1;      /* convs[l].mlp.{0,1,3} */
+  esc_bn_t bn;                                             /* batch_norms[l] */
+  esc_linear_t vlin0; esc_bn_t vbn0; esc_linear_t vlin1; esc_bn_t vbn1;   /* mlp_virtualnode_list[l].{0,1,3,4}, l < L-1 */
+  int64_t bond_row0;                                       /* first packed-table row of convs[l].edge_encoder */
+} esc_ogb_layer_t;
+typedef struct esc_ogb_gnn_t {
+  int64_t num_layers, hidden, z_rows, num_tasks;
+  int32_t residual, mean_pool;
+  float drop_ratio; int32_t pad_;
+  const float* z_table; float* dz_table;
+  esc_bn_t zbn0; esc_linear_t zlin; esc_bn_t zbn1;
+  esc_table_list tables;                                   /* atom tables first, then each layer's bond tables */
+  int64_t atom_rows, bond_rows;                            /* rows of all atom tables / of one layer's bond tables */
+  const float* vn_w; float* vn_dw;                         /* virtualnode_embedding.weight [1,H] */
+  esc_ogb_layer_t layer[ESC_MAX_LAYERS];
+  esc_linear_t head;                                       /* graph_pred_linear */
+} esc_ogb_gnn_t;
+/* a sum-of-embeddings lookup as a bag over the packed tables: CSR by output row + CSC by table row (weights all 1) */
+typedef struct esc_bag_plan_t { int64_t n_entries; const int32_t *row_ptr, *idx, *ones, *col_ptr, *c_row, *c_col; } esc_bag_plan_t;
+typedef struct esc_ogb_batch_t {
+  int64_t N, E, Z, G;
+  esc_bag_plan_t atoms, bonds;                             /* 9 entries per node / 3 per edge, indices into the packed tables
+                                                              (bonds: relative to a layer's bond_row0) */
+  const float* y;                                          /* [G, num_tasks], NaN = unlabeled (train_step only) */
+  const int32_t* graph_ptr;                                /* [G+1] */
+  const int64_t* zero_idx;                                 /* [G] zeros: virtualnode_embedding(0) for every graph (:701) */
+  const int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
+  const int32_t *row_ptr, *bag_idx, *bag_val, *col_ptr, *col_row, *col_val, *col_col;
+  uint64_t seed;                                           /* dropout stream of this step */
+} esc_ogb_batch_t;
+int64_t esc_ogb_workspace_floats(const esc_ogb_gnn_t* m, int64_t N, int64_t E, int64_t Z, int64_t G, int64_t atom_entries,
+                                 int64_t bond_entries);
+/* loss[0] = BCEWithLogits over the labeled entries (loss_denom <= 0: their count in this batch).  logits (may be NULL):
+ * float[G, num_tasks]. */
+int esc_ogb_train_step(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, int64_t loss_denom, float* loss,
+                       float* logits, void* stream);
+int esc_ogb_forward_train(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, float* logits, void* stream);
+int esc_ogb_backward(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, const float* dlogits, void* stream);
+int esc_ogb_predict(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, float* logits, void* stream);
 
 /* ---- a-5 collate (batch.py:25-149): gather B graphs out of the HBM-resident dataset store ------
  * The store keeps the reference's InMemoryDataset layout (per-key concatenation + slice pointers,

@@ -247,9 +247,11 @@ def test_zinc_variant_against_reference_golden(step_engine):
         _close_grad(n, p.grad, rp[n].grad, rp64[n].grad)
 
 
-def test_ogb_variant_against_reference_golden():
+@pytest.mark.parametrize("step_engine", [False, True], ids=["per_op", "engine"])
+def test_ogb_variant_against_reference_golden(step_engine):
     """esc_gnn_amd.ogb_mol_gnn.GNN(gnn_type='gin_eff') vs tests/golden/model_ogb.npz (reference class bodies on the
-    oracle primitives): logits, BCE loss, every gradient (fp64-oracle criterion)."""
+    oracle primitives): logits, BCE loss, every gradient (fp64-oracle criterion) — per-op autograd path and the
+    whole-step engine (csrc/engine.hip esc_ogb_*)."""
     require_gpu()
     import copy
     import esc_gnn_amd as E
@@ -264,9 +266,11 @@ def test_ogb_variant_against_reference_golden():
     assert list(m.state_dict().keys()) == keys
     m.load_state_dict(sd)
     m = m.to("cuda:0").train()
+    m.step_engine = step_engine
     _, b, _ = load_collate("molhiv4")
     bt = {k: torch.tensor(v) for k, v in b.items()}
     out = m(E.Data(**{k: v.clone() for k, v in bt.items()}))      # host batch: the model moves it (run_ogb_mol.py:58)
+    assert (type(out.grad_fn).__name__ == "_OgbEngineNodeBackward") == step_engine
     y = bt["y"].float().view(-1, 1)
     loss = torch.nn.functional.binary_cross_entropy_with_logits(out, y.to("cuda:0"))
     loss.backward()
@@ -426,3 +430,100 @@ def test_zinc_step_engine_train_step_and_predict():
     with torch.no_grad():
         e1 = m1(E.Data(**{k: v.clone() for k, v in bt.items()}))
     _close(eng.predict(E.Data(**{k: v.clone() for k, v in bt.items()})), e1.cpu(), "eval predictions")
+
+
+def _engine_uniform01(seed, n):
+    """numpy restatement of csrc/embed.hip uniform01 (the dropout stream of the OGB step engine)"""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+@pytest.mark.parametrize("p,residual,pooling", [(0.0, True, "mean"), (0.5, True, "mean"), (0.3, False, "sum")])
+def test_ogb_step_engine_matches_per_op_path(p, residual, pooling):
+    """OgbStepEngine.train_step / .predict against the per-op path of the same module — including DROPOUT: the engine
+    draws its masks from a counter-based hash; the test regenerates exactly those masks on the host and makes the per-op
+    path apply them (z_embedding's Dropout modules and the F.dropout calls of the node / virtual-node updates, in the
+    engine's numbering), so loss, logits, every gradient and the BatchNorm buffers must agree."""
+    require_gpu()
+    import copy
+    import esc_gnn_amd as E
+    from esc_gnn_amd import ogb_mol_gnn as og
+    from esc_gnn_amd.engine import OgbStepEngine
+    torch.manual_seed(11)
+    L, H = 3, 32
+    _, b, _ = load_collate("molhiv4")
+    bt = {k: torch.tensor(v) for k, v in b.items()}
+    m1 = og.GNN("ogbg-molhiv", 1, num_layer=L, emb_dim=H, gnn_type="gin_eff", virtual_node=True, residual=residual,
+                drop_ratio=p, JK="last", graph_pooling=pooling).to("cuda:0").train()
+    with torch.no_grad():
+        m1.gnn_node.virtualnode_embedding.weight.normal_(0, 0.1)      # (initialised to 0 by the reference: make it matter)
+    m2 = copy.deepcopy(m1)
+    m1.step_engine = False
+    base = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0) & ((1 << 64) - 1)      # engine._drop_seed of the first step
+
+    def mask(which, shape):
+        seed = (base * 0x2545F4914F6CDD1D + (which + 1) * 0xD1342543DE82EF95) & ((1 << 64) - 1)
+        u = _engine_uniform01(seed, int(np.prod(shape)))
+        return torch.tensor(u >= np.float32(p)).view(*shape).to("cuda:0")
+
+    calls = []
+
+    def fake_dropout(x, pp, training=True, inplace=False):
+        which = calls.pop(0)
+        return torch.where(mask(which, x.shape), x / (1.0 - p), torch.zeros_like(x)) if p > 0 else x
+
+    class _Drop(torch.nn.Module):
+        def __init__(self, which):
+            super().__init__()
+            self.which = which
+
+        def forward(self, x):
+            if p == 0 or not self.training:
+                return x
+            return torch.where(mask(self.which, x.shape), x / (1.0 - p), torch.zeros_like(x))
+
+    m1.gnn_node.z_embedding[0], m1.gnn_node.z_embedding[4] = _Drop(0), _Drop(1)
+    for l in range(L):
+        calls.append(2 + 2 * l)
+        if l < L - 1:
+            calls.append(3 + 2 * l)
+    y = bt["y"].float().view(-1, 1).clone()
+    y[1] = float("nan")                                                 # an unlabeled target
+    real = og.F.dropout
+    og.F.dropout = fake_dropout
+    try:
+        out = m1(E.Data(**{k: v.clone() for k, v in bt.items()}))
+    finally:
+        og.F.dropout = real
+    assert not calls
+    loss1 = E.ops.bce_with_logits_loss(out, y.to("cuda:0"))
+    loss1.backward()
+    eng = OgbStepEngine(m2)
+    d2 = E.Data(**{k: v.clone() for k, v in bt.items()})
+    d2.y = y.clone()
+    loss2, pred2 = eng.train_step(d2, return_pred=True)
+    _close(pred2, out.detach().cpu(), "engine logits vs per-op")
+    assert abs(float(loss1.detach()) - float(loss2)) <= 1e-5 * max(1.0, abs(float(loss1.detach())))
+    g1 = dict(m1.named_parameters())
+    for n, q in m2.named_parameters():
+        ref = g1[n].grad.cpu()
+        diff = q.grad.cpu() - ref
+        sc = max(1.0, float(ref.abs().max()))
+        ok = float(diff.abs().max()) / sc <= 2e-5 or float(diff.norm()) / max(float(ref.norm()), 1e-12) <= 5e-3   # ReLU-kink tie
+        assert ok, "grad %s: %.3g" % (n, float(diff.abs().max()) / sc)
+    b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
+    for n, a in b2.items():
+        if a.is_floating_point():
+            _close(a, b1[n].cpu(), "buffer " + n)
+    m1.eval(); m2.eval()
+    with torch.no_grad():
+        e1 = m1(E.Data(**{k: v.clone() for k, v in bt.items()}))
+    _close(eng.predict(E.Data(**{k: v.clone() for k, v in bt.items()})), e1.cpu(), "eval logits")
+    if p > 0:                                                            # a second step draws different masks
+        l3 = eng.train_step(d2)
+        assert float(l3) != float(loss2)
