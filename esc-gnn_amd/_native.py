@@ -111,7 +111,7 @@ SIGNATURES = {
     "esc_zinc_forward_train": [P, P, P, P, P],
     "esc_zinc_backward": [P, P, P, P, P],
     "esc_zinc_predict": [P, P, P, P, P],
-    "esc_segment_broadcast_add": [P, I64, P, I64, P, I64, I64, P, I64, P],
+    "esc_segment_broadcast_add": [P, I64, P, I64, P, I64, I64, I64, P, I64, P],
     "esc_dropout_fwd": [P, I64, I64, I64, ctypes.c_float, ctypes.c_uint64, P, I64, P, I64, P, P],
     "esc_dropout_bwd": [P, I64, I64, I64, ctypes.c_float, P, P, I64, P, I64, P],
     "esc_table_pack": [P, I64, P, P],

@@ -46,23 +46,36 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 }
 
 
-// out[i,:] = x[i,:] + rows[graph(i),:] — the virtual-node broadcast h + vn[batch] (ogb_mol_gnn.py:739); one wave per graph
+// out[i,:] = x[i,:] + rows[graph(i),:] — the virtual-node broadcast h + vn[batch] (ogb_mol_gnn.py:739); one thread per
+// float4 of the output, the graph of a row found by bisection of seg_ptr (G+1 ints, L1/L2 resident)
 __global__ __launch_bounds__(256) void segment_broadcast_add_kernel(const float* __restrict__ x, int64_t ld_x,
                                                                     const float* __restrict__ rows, int64_t ld_r,
                                                                     const int* __restrict__ seg_ptr, int G, int C,
                                                                     float* __restrict__ out, int64_t ld_o) {
-  const int g = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
-  if (g >= G) return;
-  const int lane = threadIdx.x & 63;
-  const int beg = seg_ptr[g], end = seg_ptr[g + 1];
-  for (int c = lane * 4; c < C; c += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(rows + (size_t)g * ld_r + c);
-    for (int r = beg; r < end; ++r) {
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (x) q = *reinterpret_cast<const float4*>(x + (size_t)r * ld_x + c);
-      *reinterpret_cast<float4*>(out + (size_t)r * ld_o + c) = make_float4(q.x + v.x, q.y + v.y, q.z + v.z, q.w + v.w);
-    }
+  const int c4 = C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = seg_ptr[G];
+  if (t >= (int64_t)n * c4) return;
+  const int r = (int)(t / c4), c = (int)(t % c4) << 2;
+  int lo = 0, hi = G;                           // last g with seg_ptr[g] <= r
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_ptr[mid] <= r) lo = mid; else hi = mid;
   }
+  const float4 v = *reinterpret_cast<const float4*>(rows + (size_t)lo * ld_r + c);
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x) q = *reinterpret_cast<const float4*>(x + (size_t)r * ld_x + c);
+  *reinterpret_cast<float4*>(out + (size_t)r * ld_o + c) = make_float4(q.x + v.x, q.y + v.y, q.z + v.z, q.w + v.w);
+}
+
+// dtable[0, c] = sum_i g[i, c] in ascending i: the gradient of a ONE-row table (virtualnode_embedding) — a thread per column
+__global__ __launch_bounds__(64) void embed_bwd_one_row_kernel(const float* __restrict__ g, int64_t ld, int64_t M, int64_t C,
+                                                               float* __restrict__ dtable) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int64_t i = 0; i < M; ++i) acc += g[i * ld + c];
+  dtable[c] = acc;
 }
 
 // counter-based uniform in [0,1): two rounds of a 64-bit mix of (seed, element index) — stateless, so the backward
@@ -141,6 +154,11 @@ int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, i
                   void* stream) {
   ESC_REQUIRE(dtable && ((g && idx) || M == 0), "esc_embed_bwd: null pointer");
   ESC_REQUIRE(rows > 0 && rows <= 4096 && C > 0 && ld_g >= C && M >= 0, "esc_embed_bwd: table of %ld rows x %ld is not a small one", (long)rows, (long)C);
+  if (rows == 1) {
+    esc::launch(ESC_K_BAG_BWD, embed_bwd_one_row_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, g, ld_g, M, C, dtable);
+    ESC_CHECK_LAUNCH("esc_embed_bwd");
+    return ESC_OK;
+  }
   int CW = 1;
   while (CW < C && CW < 256) CW <<= 1;
   esc::launch(ESC_K_BAG_BWD, embed_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, g, ld_g, idx, M, C, CW, dtable);
@@ -149,13 +167,15 @@ int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, i
 }
 
 int esc_segment_broadcast_add(const float* x, int64_t ld_x, const float* rows, int64_t ld_rows, const int32_t* seg_ptr,
-                              int64_t G, int64_t C, float* out, int64_t ld_out, void* stream) {
+                              int64_t G, int64_t n_rows, int64_t C, float* out, int64_t ld_out, void* stream) {
   ESC_REQUIRE(rows && seg_ptr && out, "esc_segment_broadcast_add: null pointer");
   ESC_REQUIRE(G > 0 && C > 0 && C % 4 == 0 && ld_rows % 4 == 0 && ld_out % 4 == 0 && (!x || ld_x % 4 == 0) && ld_out >= C,
               "esc_segment_broadcast_add: C and the leading dimensions must be multiples of 4");
   ESC_REQUIRE(aligned16(rows) && aligned16(out) && (!x || aligned16(x)), "esc_segment_broadcast_add: pointers must be 16-byte aligned");
-  esc::launch(-1, segment_broadcast_add_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, rows, ld_rows,
-              seg_ptr, (int)G, (int)C, out, ld_out);
+  ESC_REQUIRE(n_rows >= 0, "esc_segment_broadcast_add: negative row count");
+  if (n_rows == 0) return ESC_OK;
+  esc::launch(-1, segment_broadcast_add_kernel, dim3((unsigned)cdiv(n_rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x,
+              rows, ld_rows, seg_ptr, (int)G, (int)C, out, ld_out);
   ESC_CHECK_LAUNCH("esc_segment_broadcast_add");
   return ESC_OK;
 }

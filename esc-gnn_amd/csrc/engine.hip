@@ -873,7 +873,7 @@ static int forward_ogb(const OgbCtx& z) {
   for (int l = 0; l < (int)L; ++l) {
     const esc_ogb_layer_t& q = m->layer[l];
     const OgbLayer& w = y.l[l];
-    ESC_TRY(esc_segment_broadcast_add(y.h[l], H, w.vn, H, b->graph_ptr, G, H, w.hin, H, c.s));                    // :739
+    ESC_TRY(esc_segment_broadcast_add(y.h[l], H, w.vn, H, b->graph_ptr, G, N, H, w.hin, H, c.s));                    // :739
     // edge term = BondEncoder(edge_attr) + edge_encoder_pos(z_emb) (:352)
     ESC_TRY(esc_linear_fwd(y.Zemb, H, q.pos.w, H, q.pos.b, nullptr, nullptr, E, H, H, w.e, H, nullptr, c.s));
     ESC_TRY(esc_bag_fwd_acc(y.Tcat + q.bond_row0 * H, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, w.e, H, c.s));
@@ -934,7 +934,7 @@ static int backward_ogb(const OgbCtx& z) {
       ESC_TRY(linear_backward(c, y.dG1, H2, w.tmp, H, nullptr, nullptr, q.vlin0, G, y.dtmp, H, 0));
       // d vn_l = d tmp (+ d vn_{l+1} through the residual); d hin = broadcast(d tmp) (+ d h_{l+1} through the residual)
       ESC_TRY(esc_dropout_bwd(y.dtmp, H, G, H, 0.f, nullptr, m->residual ? dvn_next : nullptr, H, dvn_cur, H, c.s));
-      ESC_TRY(esc_segment_broadcast_add(m->residual ? dH : nullptr, H, y.dtmp, H, b->graph_ptr, G, H, dHin, H, c.s));
+      ESC_TRY(esc_segment_broadcast_add(m->residual ? dH : nullptr, H, y.dtmp, H, b->graph_ptr, G, N, H, dHin, H, c.s));
       have_dhin = true;
     } else if (m->residual) {
       float* t = dH; dH = dHin; dHin = t;          // d hin starts as d h_{l+1}: accumulate into that buffer

@@ -135,15 +135,19 @@ struct Cfg {
 //   chunk (l % CPR) ^ swz(row).  Offset = (o0 + row) ld 4 + chunk 16; the K-step goes through soff = kt BK 4.
 // RM tile [BK][T]: piece p holds reduction rows p RPP .. ; offset = (red0 + row) ld 4 + (o0 + col) 4; the K-step is ADDED
 //   to the offsets (it must be bounds-checked: rows past the split's end read as zero).
+// kc[j] (KC operands): k of this lane's 16-byte chunk inside a K-step — a reduction length that is not a multiple of BK
+// ends in a partial K-step whose chunks at k >= R are fetched with an out-of-range offset (they read as zero) instead of
+// running on into the next row.
 template <int T, int BK, int DW, int NP, bool RM>
-__device__ __forceinline__ void dma_offsets(int (&vo)[NP], int dw, int l, int o0, int red0, int ld) {
+__device__ __forceinline__ void dma_offsets(int (&vo)[NP], int (&kc)[NP], int dw, int l, int o0, int red0, int ld) {
   if constexpr (!RM) {
     constexpr int RB = BK * 4, CPR = RB / 16, RPP = 1024 / RB;
     const int prow = l / CPR, pc = l % CPR;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int row = (dw + DW * j) * RPP + prow;
-      vo[j] = ((o0 + row) * ld) * 4 + ((pc ^ swz<BK>(row)) << 4);
+      kc[j] = (pc ^ swz<BK>(row)) << 2;
+      vo[j] = ((o0 + row) * ld) * 4 + (kc[j] << 2);
     }
   } else {
     constexpr int RB = T * 4, CPR = RB / 16, RPP = 1024 / RB;
@@ -152,6 +156,7 @@ __device__ __forceinline__ void dma_offsets(int (&vo)[NP], int dw, int l, int o0
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int row = (dw + DW * j) * RPP + prow;
+      kc[j] = 0;
       vo[j] = ((red0 + row) * ld + o0) * 4 + (pc << 4);
     }
   }
@@ -182,9 +187,10 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
                         : make_rsrc(g.A, (unsigned)(((size_t)(g.M - 1) * g.lda + g.R) * 4));
   const i32x4 rb = B_RM ? make_rsrc(g.B, (unsigned)(((size_t)(red1 - 1) * g.ldb + g.N) * 4))
                         : make_rsrc(g.B, (unsigned)(((size_t)(g.N - 1) * g.ldb + g.R) * 4));
-  int voa[PPWA], vob[PPWB];
-  dma_offsets<BM, BK, DW, PPWA, A_RM>(voa, dw, l, m0, red0, g.lda);
-  dma_offsets<BN, BK, DW, PPWB, B_RM>(vob, dw, l, n0, red0, g.ldb);
+  int voa[PPWA], vob[PPWB], kca[PPWA], kcb[PPWB];
+  dma_offsets<BM, BK, DW, PPWA, A_RM>(voa, kca, dw, l, m0, red0, g.lda);
+  dma_offsets<BN, BK, DW, PPWB, B_RM>(vob, kcb, dw, l, n0, red0, g.ldb);
+  constexpr int OOB = 0x7FFFFFF0;                           // beyond every descriptor's num_records: the load returns 0
   const int stepa = A_RM ? BK * g.lda * 4 : 0, stepb = B_RM ? BK * g.ldb * 4 : 0;   // RM: K-step inside the checked offset
 
   const unsigned lds_base = lds_addr(lds);
@@ -192,15 +198,21 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   auto stage = [&](int buf) {
     const unsigned a_dst = lds_base + (unsigned)(buf * C_::STAGE_FLOATS + dw * 256) * 4u;
     const unsigned b_dst = a_dst + C_::A_FLOATS * 4u;
-    const int soff = (red0 + issued * BK) * 4;              // KC operands: K offset, never out of range
+    const int k0 = red0 + issued * BK;                      // first reduction index of this K-step
+    const int soff = k0 * 4;                                // KC operands: K offset (an SGPR offset is not range-checked)
+    const bool tail = k0 + BK > red1;                       // wave-uniform: the partial last K-step of a KC operand
 #pragma unroll
     for (int j = 0; j < PPWA; ++j) {
-      dma16(ra, a_dst + (unsigned)(DW * j) * 1024u, voa[j], A_RM ? 0 : soff);
+      int vo = voa[j];
+      if constexpr (!A_RM) { if (tail && k0 + kca[j] >= red1) vo = OOB; }
+      dma16(ra, a_dst + (unsigned)(DW * j) * 1024u, vo, A_RM ? 0 : soff);
       if constexpr (A_RM) voa[j] += stepa;
     }
 #pragma unroll
     for (int j = 0; j < PPWB; ++j) {
-      dma16(rb, b_dst + (unsigned)(DW * j) * 1024u, vob[j], B_RM ? 0 : soff);
+      int vo = vob[j];
+      if constexpr (!B_RM) { if (tail && k0 + kcb[j] >= red1) vo = OOB; }
+      dma16(rb, b_dst + (unsigned)(DW * j) * 1024u, vo, B_RM ? 0 : soff);
       if constexpr (B_RM) vob[j] += stepb;
     }
     ++issued;
@@ -227,10 +239,12 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
       bn_fold_column(g.fold, k, wg == 0, sc, sh);
       pro[k] = sc; pro[C_::PRO_MAXK + k] = sh;
     }
+    for (int k = g.R + threadIdx.x; k < ((g.R + BK - 1) / BK) * BK; k += C_::NTHR) { pro[k] = 0.f; pro[C_::PRO_MAXK + k] = 0.f; }   // partial last K-step: relu(0*0+0) = 0
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   if constexpr (PRO == 1) {
     for (int k = threadIdx.x; k < g.R; k += C_::NTHR) { pro[k] = g.pro_scale[k]; pro[C_::PRO_MAXK + k] = g.pro_shift[k]; }
+    for (int k = g.R + threadIdx.x; k < ((g.R + BK - 1) / BK) * BK; k += C_::NTHR) { pro[k] = 0.f; pro[C_::PRO_MAXK + k] = 0.f; }   // partial last K-step
     // the raw s_barrier of the first K-step publishes these writes: they must have LANDED before this wave arrives there
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }

@@ -949,7 +949,7 @@ static void dma_wgrad_plan(int64_t M, int64_t N, int64_t K, int bm, int bn, int*
 static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias, const float* in_scale,
                     const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y, float* col_stats,
                     hipStream_t s, int* rc) {
-  if (!(g_use_dma & 1) || K % 32 != 0 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && K > 1280)) return false;
+  if (!(g_use_dma & 1) || K % 4 != 0 || K < 32 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && cdiv(K, 32) * 32 > 1280)) return false;
   if (N <= 32 && (!(g_use_dma & 8) || col_stats != nullptr || in_scale != nullptr)) return false;
   dma::GArgs g{};
   g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
@@ -972,7 +972,7 @@ static bool dma_bwd_ok(const float* dY, int64_t ld_dy, const float* X, int64_t l
                        int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx, const float* slabs, bool need_dx,
                        bool need_dw) {
   if (!(g_use_dma & 2) || N <= 32 || K <= 32 || N % 4 != 0 || K % 4 != 0 || !dma_ok(dY, M, ld_dy)) return false;
-  if (need_dx && (N % 32 != 0 || !dma_ok(W, N, ld_w) || !dma_ok(dX, M, ld_dx))) return false;
+  if (need_dx && (!dma_ok(W, N, ld_w) || !dma_ok(dX, M, ld_dx))) return false;      // (N % 4 == 0 checked above: partial last K-step)
   if (need_dw && (!dma_ok(X, M, ld_x) || !aligned16(slabs))) return false;
   return true;
 }
@@ -1106,7 +1106,7 @@ int esc_linear_fold_available(void) { return (g_use_dma & 1) != 0; }
 int64_t esc_linear_stats_block_rows(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N,
                                     int64_t K) {
   if ((g_use_dma & 4) && K <= small::SMALL_MAX && N > 32) return small::ROWS_FWD;
-  if ((g_use_dma & 1) && K % 32 == 0 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w)) return (M >= 8192 && N >= 128) ? 128 : 64;
+  if ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w)) return (M >= 8192 && N >= 128) ? 128 : 64;
   return 32;
 }
 
@@ -1128,7 +1128,7 @@ int esc_linear_fwd_fold(const float* X, int64_t ld_x, const float* W, int64_t ld
     ESC_CHECK_LAUNCH("esc_linear_fwd_fold.narrow");
     return ESC_OK;
   }
-  ESC_REQUIRE((g_use_dma & 1) && K % 32 == 0 && K <= 1280 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w),
+  ESC_REQUIRE((g_use_dma & 1) && K % 4 == 0 && K >= 32 && cdiv(K, 32) * 32 <= 1280 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w),
               "esc_linear_fwd_fold: shape not served by the folding kernels (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
   dma::GArgs g{};
   g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;

@@ -113,6 +113,27 @@ __global__ __launch_bounds__(256) void plan_count_kernel(const int64_t* __restri
   atomicAdd(&counts[k], 1);
 }
 
+// few keys (embedding tables, graph ids): thousands of positions hit the same counters — count a chunk in LDS first and
+// add each non-zero bin once (integer adds: the result does not depend on the order)
+constexpr int PLAN_SMALL_KEYS = 2048;
+__global__ __launch_bounds__(256) void plan_count_small_kernel(const int64_t* __restrict__ key, int64_t n, int n_keys,
+                                                               int* __restrict__ counts, int* __restrict__ bad) {
+  __shared__ int cnt[PLAN_SMALL_KEYS];
+  for (int k = threadIdx.x; k < n_keys; k += 256) cnt[k] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (PLAN_CHUNK * 4);
+  for (int t = threadIdx.x; t < PLAN_CHUNK * 4; t += 256) {
+    const int64_t i = base + t;
+    if (i < n) {
+      const int64_t k = key[i];
+      if (k < 0 || k >= n_keys) *bad = 1; else atomicAdd(&cnt[(int)k], 1);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_keys; k += 256)
+    if (cnt[k]) atomicAdd(&counts[k], cnt[k]);
+}
+
 }  // namespace esc
 
 using namespace esc;
@@ -140,7 +161,10 @@ int esc_plan_csr(const int64_t* key, int64_t n, int64_t n_keys, int32_t* ptr, in
     set_error("esc_plan_csr: memset failed");
     return ESC_ELAUNCH;
   }
-  if (n > 0) esc::launch(ESC_K_COLLATE, plan_count_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, key, n, n_keys, counts, bad_flag);
+  if (n > 0 && n_keys <= PLAN_SMALL_KEYS)
+    esc::launch(ESC_K_COLLATE, plan_count_small_kernel, dim3((unsigned)cdiv(n, PLAN_CHUNK * 4)), dim3(256), 0, s, key, n, (int)n_keys, counts, bad_flag);
+  else if (n > 0)
+    esc::launch(ESC_K_COLLATE, plan_count_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, key, n, n_keys, counts, bad_flag);
   esc::launch(ESC_K_COLLATE, plan_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)counts, n_keys, ptr, 1);
   ESC_CHECK_LAUNCH("esc_plan_csr.ptr");
   if (n == 0 || perm == nullptr) return ESC_OK;        // perm == NULL: segment pointers only (keys already grouped)

@@ -403,9 +403,10 @@ int esc_embed_fwd(const float* table, int64_t rows, int64_t C, const int64_t* id
                   int32_t* bad_flag, void* stream);
 int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, int64_t rows, int64_t C, float* dtable,
                   void* stream);
-/* out[i,:] = x[i,:] (0 if x == NULL) + rows[graph(i),:]: the virtual-node broadcast h + vn[batch] (ogb_mol_gnn.py:739) */
+/* out[i,:] = x[i,:] (0 if x == NULL) + rows[graph(i),:] for the n_rows = seg_ptr[G] rows: the virtual-node broadcast
+ * h + vn[batch] (ogb_mol_gnn.py:739) */
 int esc_segment_broadcast_add(const float* x, int64_t ld_x, const float* rows, int64_t ld_rows, const int32_t* seg_ptr,
-                              int64_t G, int64_t C, float* out, int64_t ld_out, void* stream);
+                              int64_t G, int64_t n_rows, int64_t C, float* out, int64_t ld_out, void* stream);
 /* y = F.dropout(x, p, training=True) (+ res): keep with probability 1-p and scale by 1/(1-p); the keep mask (one byte
  * per element, [M*C]) is written for the backward.  The stream of random numbers is a counter-based hash of (seed,
  * element index) — NOT torch's generator: masks differ from the reference's, their distribution does not.  p == 0 is

@@ -92,7 +92,8 @@ def test_aggregate_forward_bit_exact_and_backward(E, C):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (333, 256, 10), (777, 10, 256), (130, 256, 1280),
-                                   (257, 1, 256), (9000, 256, 256), (5, 48, 36)])
+                                   (257, 1, 256), (9000, 256, 256), (5, 48, 36),
+                                   (1000, 300, 300), (777, 600, 300), (9000, 300, 600), (6500, 300, 44), (260, 36, 300)])
 def test_linear_forward_backward(E, M, N, K):
     torch.manual_seed(M + N + K)
     dev = torch.device("cuda:0")
@@ -270,7 +271,7 @@ def test_gineplus_against_message_passing_loop(E):
 
 
 @pytest.mark.parametrize("M,N,K", [(15200, 256, 256), (2400, 256, 256), (2401, 256, 1280), (333, 256, 10), (50, 300, 64),
-                                   (33, 64, 16), (31, 40, 8)])
+                                   (33, 64, 16), (31, 40, 8), (2400, 300, 300), (9000, 600, 300), (256, 300, 600)])
 @pytest.mark.parametrize("last_block", [0, 1])
 def test_linear_with_fused_batchnorm_statistics(E, M, N, K, last_block):
     """esc_linear_bn_fwd: GEMM + statistics epilogue + merge (finalize launch, or knob 8: by the last workgroups of
@@ -306,7 +307,8 @@ def test_linear_with_fused_batchnorm_statistics(E, M, N, K, last_block):
     _chk(rvd, 0.9 * rv0.double() + 0.1 * r.var(0, unbiased=True), "running_var")
 
 
-@pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (2401, 256, 10), (333, 64, 64), (15200, 256, 256), (97, 128, 1280)])
+@pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (2401, 256, 10), (333, 64, 64), (15200, 256, 256), (97, 128, 1280),
+                                   (333, 64, 300)])
 def test_batchnorm_folded_into_its_consumer(E, M, N, K):
     """esc_linear_fwd leaves BatchNorm partials (block height = esc_linear_stats_block_rows); the consumers merge them in
     their prologue: esc_linear_fwd_fold (MFMA tile and the wave-per-row narrow form) and esc_affine_act_fold, against fp64
