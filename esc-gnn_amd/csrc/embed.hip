@@ -21,30 +21,59 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(out + i * ld + c) = v;
 }
 
-// dtable[r, c] = sum_{i: idx[i] == r} g[i, c]; one workgroup per table row, thread (rg, c) walks i = rg, rg+RG, ...
-// and the RG partial sums are added in ascending rg.
+// dtable[r, c] = sum_{i: idx[i] == r} g[i, c]; one workgroup per table row.  Pass over the index vector in slices of
+// EMB_SLICE positions: each wave scans its quarter of the slice with coalesced loads and appends the matching positions
+// to its own LDS list (ballot compaction, ascending); then thread (rg, c) adds the listed rows rg, rg+RG, ... and the RG
+// partial sums are combined in ascending rg — a fixed order, bitwise reproducible.
+constexpr int EMB_SLICE = 8192;
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, int64_t ld, const int64_t* __restrict__ idx,
                                                         int64_t M, int64_t C, int CW, float* __restrict__ dtable) {
+  __shared__ int list[4][EMB_SLICE / 4];
+  __shared__ int cnt[4];
   __shared__ float part[256];
   const int r = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = threadIdx.x % CW, rg = threadIdx.x / CW, RG = 256 / CW;
   for (int64_t c0 = 0; c0 < C; c0 += CW) {
     const int64_t col = c0 + c;
     float acc = 0.f;
-    if (col < C)
-      for (int64_t i = rg; i < M; i += RG)
-        if (idx[i] == r) acc += g[i * ld + col];
+    for (int64_t s0 = 0; s0 < M; s0 += EMB_SLICE) {
+      const int64_t q0 = s0 + (int64_t)wave * (EMB_SLICE / 4);
+      int n = 0;
+      for (int t = 0; t < EMB_SLICE / 4; t += 64) {
+        const int64_t i = q0 + t + lane;
+        const bool hit = i < M && idx[i] == r;
+        const unsigned long long m = __ballot(hit);
+        if (hit) list[wave][n + __popcll(m & ((1ull << lane) - 1ull))] = (int)(i - s0);
+        n += __popcll(m);
+        if (q0 + t + 64 >= M) break;                      // wave-uniform
+      }
+      if (lane == 0) cnt[wave] = n;
+      __syncthreads();
+      if (col < C) {
+        for (int w = 0; w < 4; ++w) {                      // wave-major = ascending position
+          const int nw = cnt[w];
+          int j = rg;
+          for (; j + 3 * RG < nw; j += 4 * RG) {
+            const float a0 = g[(s0 + list[w][j]) * ld + col], a1 = g[(s0 + list[w][j + RG]) * ld + col];
+            const float a2 = g[(s0 + list[w][j + 2 * RG]) * ld + col], a3 = g[(s0 + list[w][j + 3 * RG]) * ld + col];
+            acc += a0; acc += a1; acc += a2; acc += a3;
+          }
+          for (; j < nw; j += RG) acc += g[(s0 + list[w][j]) * ld + col];
+        }
+      }
+      __syncthreads();
+    }
     part[threadIdx.x] = acc;
     __syncthreads();
     if (rg == 0 && col < C) {
-      float s = part[c];
-      for (int k = 1; k < RG; ++k) s += part[k * CW + c];
-      dtable[(int64_t)r * C + col] = s;
+      float sum = part[c];
+      for (int k = 1; k < RG; ++k) sum += part[k * CW + c];
+      dtable[(int64_t)r * C + col] = sum;
     }
     __syncthreads();
   }
 }
-
 
 // out[i,:] = x[i,:] + rows[graph(i),:] — the virtual-node broadcast h + vn[batch] (ogb_mol_gnn.py:739); one thread per
 // float4 of the output, the graph of a row found by bisection of seg_ptr (G+1 ints, L1/L2 resident)
@@ -68,14 +97,19 @@ __global__ __launch_bounds__(256) void segment_broadcast_add_kernel(const float*
   *reinterpret_cast<float4*>(out + (size_t)r * ld_o + c) = make_float4(q.x + v.x, q.y + v.y, q.z + v.z, q.w + v.w);
 }
 
-// dtable[0, c] = sum_i g[i, c] in ascending i: the gradient of a ONE-row table (virtualnode_embedding) — a thread per column
-__global__ __launch_bounds__(64) void embed_bwd_one_row_kernel(const float* __restrict__ g, int64_t ld, int64_t M, int64_t C,
+// dtable[0, c] = sum_i g[i, c]: the gradient of a ONE-row table (virtualnode_embedding).  64 columns x 4 row groups per
+// workgroup; group q sums rows q, q+4, ... and the four partial sums are added in order
+__global__ __launch_bounds__(256) void embed_bwd_one_row_kernel(const float* __restrict__ g, int64_t ld, int64_t M, int64_t C,
                                                                float* __restrict__ dtable) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float part[256];
+  const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int q = threadIdx.x >> 6;
   float acc = 0.f;
-  for (int64_t i = 0; i < M; ++i) acc += g[i * ld + c];
-  dtable[c] = acc;
+  if (c < C)
+    for (int64_t i = q; i < M; i += 4) acc += g[i * ld + c];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (q == 0 && c < C) dtable[c] = ((part[threadIdx.x] + part[threadIdx.x + 64]) + part[threadIdx.x + 128]) + part[threadIdx.x + 192];
 }
 
 // counter-based uniform in [0,1): two rounds of a 64-bit mix of (seed, element index) — stateless, so the backward
@@ -88,9 +122,9 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-// y = dropout_p(x) + res:  keep with probability 1-p, scale by 1/(1-p) (torch.nn.functional.dropout); p == 0: y = x + res
+// y = dropout_p(x) + res:  keep with probability 1-p, multiply by scale = 1/(1-p) (torch.nn.functional.dropout); p == 0: y = x + res
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, int64_t ld_x, int64_t M, int C, float p,
-                                                          unsigned long long seed, const float* __restrict__ res, int64_t ld_r,
+                                                          float scale, unsigned long long seed, const float* __restrict__ res, int64_t ld_r,
                                                           float* __restrict__ y, int64_t ld_y, unsigned char* __restrict__ mask) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= M * C) return;
@@ -100,7 +134,7 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restric
   if (p > 0.f) {
     const bool keep = uniform01(seed, (unsigned long long)t) >= p;
     mask[t] = keep ? 1 : 0;
-    v = keep ? v / (1.f - p) : 0.f;
+    v = keep ? v * scale : 0.f;
   }
   if (res) v += res[r * ld_r + c];
   y[r * ld_y + c] = v;
@@ -108,14 +142,14 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restric
 
 // dx = dy * mask / (1-p)  (+ add, when given: the other branch of a residual sum)
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, int64_t ld_dy, int64_t M, int C, float p,
-                                                          const unsigned char* __restrict__ mask, const float* __restrict__ add,
+                                                          float scale, const unsigned char* __restrict__ mask, const float* __restrict__ add,
                                                           int64_t ld_a, float* __restrict__ dx, int64_t ld_dx) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= M * C) return;
   const int64_t r = t / C;
   const int c = (int)(t % C);
   float v = dy[r * ld_dy + c];
-  if (p > 0.f) v = mask[t] ? v / (1.f - p) : 0.f;
+  if (p > 0.f) v = mask[t] ? v * scale : 0.f;
   if (add) v += add[r * ld_a + c];
   dx[r * ld_dx + c] = v;
 }
@@ -155,7 +189,7 @@ int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, i
   ESC_REQUIRE(dtable && ((g && idx) || M == 0), "esc_embed_bwd: null pointer");
   ESC_REQUIRE(rows > 0 && rows <= 4096 && C > 0 && ld_g >= C && M >= 0, "esc_embed_bwd: table of %ld rows x %ld is not a small one", (long)rows, (long)C);
   if (rows == 1) {
-    esc::launch(ESC_K_BAG_BWD, embed_bwd_one_row_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, g, ld_g, M, C, dtable);
+    esc::launch(ESC_K_BAG_BWD, embed_bwd_one_row_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, g, ld_g, M, C, dtable);
     ESC_CHECK_LAUNCH("esc_embed_bwd");
     return ESC_OK;
   }
@@ -186,7 +220,7 @@ int esc_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int64_t C, float p,
   ESC_REQUIRE(M >= 0 && C > 0 && C < (1LL << 31) && p >= 0.f && p < 1.f, "esc_dropout_fwd: bad arguments (p=%g)", (double)p);
   if (M == 0) return ESC_OK;
   esc::launch(-1, dropout_fwd_kernel, dim3((unsigned)cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, M, (int)C, p,
-              (unsigned long long)seed, res, ld_res, y, ld_y, (unsigned char*)mask);
+              (float)(1.0 / (1.0 - (double)p)), (unsigned long long)seed, res, ld_res, y, ld_y, (unsigned char*)mask);
   ESC_CHECK_LAUNCH("esc_dropout_fwd");
   return ESC_OK;
 }
@@ -197,7 +231,7 @@ int esc_dropout_bwd(const float* dy, int64_t ld_dy, int64_t M, int64_t C, float 
   ESC_REQUIRE(M >= 0 && C > 0 && C < (1LL << 31) && p >= 0.f && p < 1.f, "esc_dropout_bwd: bad arguments (p=%g)", (double)p);
   if (M == 0) return ESC_OK;
   esc::launch(-1, dropout_bwd_kernel, dim3((unsigned)cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, M, (int)C, p,
-              (const unsigned char*)mask, add, ld_add, dx, ld_dx);
+              (float)(1.0 / (1.0 - (double)p)), (const unsigned char*)mask, add, ld_add, dx, ld_dx);
   ESC_CHECK_LAUNCH("esc_dropout_bwd");
   return ESC_OK;
 }

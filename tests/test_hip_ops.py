@@ -421,3 +421,115 @@ def test_reduce_sum_jobs(E):
     nv.call("esc_reduce_sum_jobs", ctypes.cast(jobs, ctypes.c_void_p), len(vecs), nv.stream())
     want = torch.tensor([float(v.double().sum()) for v in vecs])
     assert torch.allclose(outs.cpu().double(), want.double(), rtol=1e-6, atol=1e-6)
+
+
+# ---- building blocks of the ZINC / OGB step engines (csrc/embed.hip, bag.hip) -------------------------------------------
+@pytest.mark.parametrize("M,rows,C", [(6400, 100, 32), (2400, 28, 32), (20000, 5, 300), (256, 1, 300), (3, 7, 8), (17000, 3, 64)])
+def test_small_table_embedding_kernels(E, M, rows, C):
+    """esc_embed_fwd / esc_embed_bwd (type-embedding lookups of zinc_models.py:581,591) against index_select / index_add_
+    in fp64; the gradient is bitwise reproducible; an out-of-range index yields a zero row and raises the flag."""
+    from esc_gnn_amd import _native as nv
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator().manual_seed(M + rows)
+    table = torch.randn(rows, C, generator=g0)
+    idx = torch.randint(0, rows, (M,), generator=g0)
+    if M > 10:
+        idx[: M // 2] = idx[0]                                   # one dominant type, like carbon
+    td, idd = table.to(dev), idx.to(dev)
+    ld = C + 4
+    out = torch.zeros(M, ld, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    nv.call("esc_embed_fwd", nv.ptr(td), rows, C, nv.ptr(idd), M, nv.ptr(out), ld, nv.ptr(bad), nv.stream())
+    assert torch.equal(out[:, :C].cpu(), table[idx]) and int(bad.item()) == 0 and float(out[:, C:].abs().max()) == 0
+    gr = torch.randn(M, ld, generator=g0)
+    grd = gr.to(dev)
+    dts = []
+    for _ in range(2):
+        dt = torch.full((rows, C), float("nan"), device=dev)
+        nv.call("esc_embed_bwd", nv.ptr(grd), ld, nv.ptr(idd), M, rows, C, nv.ptr(dt), nv.stream())
+        dts.append(dt.cpu())
+    want = torch.zeros(rows, C, dtype=torch.float64).index_add_(0, idx, gr[:, :C].double())
+    assert torch.equal(dts[0], dts[1])
+    assert torch.allclose(dts[0].double(), want, rtol=1e-5, atol=1e-5 * max(1.0, float(want.abs().max())))
+    idd2 = idd.clone(); idd2[M // 2] = rows
+    nv.call("esc_embed_fwd", nv.ptr(td), rows, C, nv.ptr(idd2), M, nv.ptr(out), ld, nv.ptr(bad), nv.stream())
+    assert int(bad.item()) == 1 and float(out[M // 2].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,C,p", [(20000, 300, 0.65), (6500, 300, 0.5), (256, 300, 0.0), (1000, 64, 0.1)])
+def test_dropout_kernels(E, M, C, p):
+    """esc_dropout_fwd / _bwd: keep rate 1-p, kept values scaled by 1/(1-p), the optional residual added after the
+    dropout, backward = the same mask; a different seed draws a different mask, the same seed the same one."""
+    from esc_gnn_amd import _native as nv
+    dev = torch.device("cuda:0")
+    x = torch.randn(M, C, device=dev) + 3.0
+    res = torch.randn(M, C, device=dev)
+    y, y2, y3 = (torch.empty(M, C, device=dev) for _ in range(3))
+    m1, m2, m3 = (torch.zeros(M * C, dtype=torch.uint8, device=dev) for _ in range(3))
+    nv.call("esc_dropout_fwd", nv.ptr(x), C, M, C, p, 1234, nv.ptr(res), C, nv.ptr(y), C, nv.ptr(m1), nv.stream())
+    nv.call("esc_dropout_fwd", nv.ptr(x), C, M, C, p, 1234, None, 0, nv.ptr(y2), C, nv.ptr(m2), nv.stream())
+    nv.call("esc_dropout_fwd", nv.ptr(x), C, M, C, p, 99, None, 0, nv.ptr(y3), C, nv.ptr(m3), nv.stream())
+    if p == 0:
+        assert torch.equal(y, x + res) and torch.equal(y2, x)
+        return
+    keep = m1.view(M, C).bool()
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / (M * C)) ** 0.5 + 1e-3
+    scale = float(np.float32(1.0 / (1.0 - float(np.float32(p)))))
+    assert torch.equal(y2, torch.where(keep, x * scale, torch.zeros_like(x)))
+    assert torch.equal(y, y2 + res)
+    col_rate = keep.float().mean(0)                              # no column or row structure in the mask
+    assert float(col_rate.min()) > (1 - p) - 0.05 and float(col_rate.max()) < (1 - p) + 0.05
+    dy = torch.randn(M, C, device=dev)
+    dx = torch.empty(M, C, device=dev)
+    nv.call("esc_dropout_bwd", nv.ptr(dy), C, M, C, p, nv.ptr(m1), nv.ptr(res), C, nv.ptr(dx), C, nv.stream())
+    assert torch.equal(dx, torch.where(keep, dy * scale, torch.zeros_like(dy)) + res)
+
+
+def test_broadcast_add_table_pack_and_accumulating_bag(E):
+    """esc_segment_broadcast_add (h + vn[batch]), esc_table_pack / _unpack_grad and esc_bag_fwd_acc against torch"""
+    import ctypes
+    from esc_gnn_amd import _native as nv
+    from esc_gnn_amd.engine import _TableList
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator().manual_seed(5)
+    sizes = torch.randint(1, 40, (300,), generator=g0)
+    sizes[7] = 0 if False else sizes[7]
+    ptr = torch.zeros(301, dtype=torch.int32); ptr[1:] = torch.cumsum(sizes, 0)
+    N, G, C = int(ptr[-1]), 300, 300
+    x, rows = torch.randn(N, C, generator=g0), torch.randn(G, C, generator=g0)
+    batch = torch.repeat_interleave(torch.arange(G), sizes)
+    out = torch.empty(N, C, device=dev)
+    xd, rd, pd = x.to(dev), rows.to(dev), ptr.to(dev)
+    nv.call("esc_segment_broadcast_add", nv.ptr(xd), C, nv.ptr(rd), C, nv.ptr(pd), G, N, C, nv.ptr(out), C, nv.stream())
+    assert torch.equal(out.cpu(), x + rows[batch])
+    nv.call("esc_segment_broadcast_add", None, 0, nv.ptr(rd), C, nv.ptr(pd), G, N, C, nv.ptr(out), C, nv.stream())
+    assert torch.equal(out.cpu(), rows[batch])
+    # tables
+    dims = (119, 5, 12, 2)
+    tabs = [torch.randn(d, C, generator=g0).to(dev) for d in dims]
+    grads = [torch.zeros(d, C, device=dev) for d in dims]
+    tl = _TableList()
+    tl.count = len(dims)
+    for j, (t, gr) in enumerate(zip(tabs, grads)):
+        tl.rows[j], tl.w[j], tl.dw[j] = t.size(0), t.data_ptr(), gr.data_ptr()
+    cat = torch.empty(sum(dims), C, device=dev)
+    nv.call("esc_table_pack", ctypes.byref(tl), C, nv.ptr(cat), nv.stream())
+    assert torch.equal(cat, torch.cat(tabs))
+    dcat = torch.randn(sum(dims), C, device=dev)
+    nv.call("esc_table_unpack_grad", ctypes.byref(tl), C, nv.ptr(dcat), nv.stream())
+    assert torch.equal(torch.cat(grads), dcat)
+    # bag that adds onto its output
+    n = 500
+    index = torch.stack([torch.randint(0, d, (n,), generator=g0) for d in dims], 1).to(dev)
+    plan = E.ops.embed_plan(index, dims)
+    base = torch.randn(n, C, device=dev)
+    acc = base.clone()
+    nv.call("esc_bag_fwd_acc", nv.ptr(cat), C, nv.ptr(plan["row_ptr"]), nv.ptr(plan["idx32"]), nv.ptr(plan["ones"]), n, nv.ptr(acc), C,
+            nv.stream())
+    want = base.clone()
+    offs = [0, 119, 124, 136]
+    for j in range(len(dims)):
+        want = want + cat[index[:, j] + offs[j]]
+    assert torch.equal(acc, want)
