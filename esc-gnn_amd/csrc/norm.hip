@@ -376,7 +376,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // Row-strided float4 form of the two elementwise passes above: a lane owns one column quad for the whole launch, so
 // the per-column coefficients are loaded ONCE as float4 (the flat-index kernels re-read ~20 scalars per element) and a
 // wave keeps 4 rows x 2-3 arrays in flight.  Edge-sized BatchNorm backward: 17 -> 11 us.
-template <int ACT, bool HAS_Y>
+// FOLD: there was no finalize launch — `coef` is the partial-sum array [fold_slots][C] of bn_bwd_partial_kernel_v4 and
+// every wave adds the (few) slots of its four columns itself, in slot order with fp64 accumulators like the finalize
+// kernel; the first row block also writes dgamma / dbeta.  Node-sized BatchNorms only (<= 32 slots): a dependent launch
+// costs more than 64 extra loads per lane.
+template <int ACT, bool HAS_Y, bool FOLD = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict__ X, int64_t ldx,
                                                          const float* __restrict__ Y, int64_t ldy,
                                                          const float* __restrict__ dY, int64_t ldg, int M, int C,
@@ -385,7 +389,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          const float2* __restrict__ coef,
-                                                         float* __restrict__ dX, int64_t ldd) {
+                                                         float* __restrict__ dX, int64_t ldd, int fold_slots = 0,
+                                                         float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
   ESC_PRIO();
   constexpr int relu = ACT;
   const int c = (blockIdx.x * 64 + lane_id()) * 4;
@@ -395,7 +400,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
   const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
   const float4 ga = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 be = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 k01 = *reinterpret_cast<const float4*>(coef + c), k23 = *reinterpret_cast<const float4*>(coef + c + 2);
+  float4 k01, k23;
+  if constexpr (FOLD) {
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int p = 0; p < fold_slots; ++p) {
+      const float4 u = *reinterpret_cast<const float4*>(coef + (size_t)p * C + c), v = *reinterpret_cast<const float4*>(coef + (size_t)p * C + c + 2);
+      s1[0] += (double)u.x; s2[0] += (double)u.y; s1[1] += (double)u.z; s2[1] += (double)u.w;
+      s1[2] += (double)v.x; s2[2] += (double)v.y; s1[3] += (double)v.z; s2[3] += (double)v.w;
+    }
+    k01 = make_float4((float)(s1[0] / M), (float)(s2[0] / M), (float)(s1[1] / M), (float)(s2[1] / M));
+    k23 = make_float4((float)(s1[2] / M), (float)(s2[2] / M), (float)(s1[3] / M), (float)(s2[3] / M));
+    if (slot == 0) {
+      if (dgamma) *reinterpret_cast<float4*>(dgamma + c) = make_float4((float)s2[0], (float)s2[1], (float)s2[2], (float)s2[3]);
+      if (dbeta) *reinterpret_cast<float4*>(dbeta + c) = make_float4((float)s1[0], (float)s1[1], (float)s1[2], (float)s1[3]);
+    }
+  } else {
+    k01 = *reinterpret_cast<const float4*>(coef + c); k23 = *reinterpret_cast<const float4*>(coef + c + 2);
+  }
   const float4 a = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
 #pragma unroll 4
   for (int r = slot; r < M; r += P) {
@@ -762,7 +784,7 @@ static int bn_bwd_apply_impl(const float* X, int64_t ld_x, const float* Y, int64
   const bool rows_form = vec && aligned16(mean) && aligned16(invstd) && (!beta || aligned16(beta)) && aligned16(coef);
   if (rows_form) {
     const dim3 grid((unsigned)cdiv(C, 256), (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048));
-#define ESC_BWD_ROWS(A, H) esc::launch(ESC_K_NORM, bn_bwd_apply_rows<A, H>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, coef, dX, ld_dx)
+#define ESC_BWD_ROWS(A, H) esc::launch(ESC_K_NORM, bn_bwd_apply_rows<A, H, false>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, coef, dX, ld_dx, 0, (float*)nullptr, (float*)nullptr)
     if (relu == 0)      ESC_BWD_ROWS(0, false);
     else if (relu == 1) { if (Y) ESC_BWD_ROWS(1, true); else ESC_BWD_ROWS(1, false); }
     else                { if (Y) ESC_BWD_ROWS(2, true); else ESC_BWD_ROWS(2, false); }
@@ -784,6 +806,31 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   hipStream_t s = (hipStream_t)stream;
   float2* partial = (float2*)scratch;
   float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
+  // node-sized: 32 fat row blocks leave 32 partial slots and the apply kernel adds them itself — no finalize launch
+  const bool all16 = aligned16(X) && aligned16(dY) && aligned16(dX) && (!Y || aligned16(Y)) && aligned16(mean) && aligned16(invstd) &&
+                     (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && aligned16(partial) &&
+                     (!dgamma || aligned16(dgamma)) && (!dbeta || aligned16(dbeta));
+  if (bn_bwd_fold() && M >= 64 && M <= 4096 && C % 4 == 0 && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0 && (!Y || ld_y % 4 == 0) && all16 &&
+      !last_block_finalize()) {
+    const int rb = (int)(cdiv(M, 32) < 32 ? cdiv(M, 32) : 32);
+    const dim3 grid((unsigned)cdiv(C, 256), rb);
+    float* nof = nullptr; float2* noc = nullptr; unsigned* tk = nullptr;
+#define ESC_BWD_PARTIAL(A, H) esc::launch(ESC_K_NORM, bn_bwd_partial_kernel_v4<A, H>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial, tk, nof, nof, noc)
+    if (relu == 0)      ESC_BWD_PARTIAL(0, false);
+    else if (relu == 1) { if (Y) ESC_BWD_PARTIAL(1, true); else ESC_BWD_PARTIAL(1, false); }
+    else                { if (Y) ESC_BWD_PARTIAL(2, true); else ESC_BWD_PARTIAL(2, false); }
+#undef ESC_BWD_PARTIAL
+    ESC_CHECK_LAUNCH("esc_bn_bwd.partial");
+    const dim3 agrid((unsigned)cdiv(C, 256), (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048));
+    const float2* cpart = partial;
+#define ESC_BWD_ROWS(A, H) esc::launch(ESC_K_NORM, bn_bwd_apply_rows<A, H, true>, agrid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, cpart, dX, ld_dx, rb, dgamma, dbeta)
+    if (relu == 0)      ESC_BWD_ROWS(0, false);
+    else if (relu == 1) { if (Y) ESC_BWD_ROWS(1, true); else ESC_BWD_ROWS(1, false); }
+    else                { if (Y) ESC_BWD_ROWS(2, true); else ESC_BWD_ROWS(2, false); }
+#undef ESC_BWD_ROWS
+    ESC_CHECK_LAUNCH("esc_bn_bwd.apply_fold");
+    return ESC_OK;
+  }
   int rc = bn_bwd_reduce(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, M, true, dgamma, dbeta, partial, coef, s);
   if (rc != ESC_OK) return rc;
   return bn_bwd_apply_impl(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, coef, dX, ld_dx, s);

@@ -56,6 +56,9 @@ static int g_edge_lds_floor = 52 * 1024;      // 3 edge-GEMM workgroups per CU: 
 int edge_lds_floor() { return g_edge_lds_floor; }
 void set_edge_lds_floor(int bytes) { g_edge_lds_floor = bytes < 0 ? 0 : bytes; }
 
+static int g_bn_bwd_fold = 0;      // measured on MI355X r02: 1.298 ms with it vs 1.215 ms without (the 32-block partial pass is slower than what the finalize launch costs)
+bool bn_bwd_fold() { return g_bn_bwd_fold != 0; }
+void set_bn_bwd_fold(int on) { g_bn_bwd_fold = on != 0; }
 static int g_norm_rowblock_cap = 256;
 int norm_rowblock_cap() { return g_norm_rowblock_cap; }
 void set_norm_rowblock_cap(int v) { g_norm_rowblock_cap = v < 1 ? 1 : (v > 512 ? 512 : v); }
