@@ -772,7 +772,7 @@ struct OgbLayout {
   float *pooled, *logits, *dlogits;
   // backward
   float *dpooled, *dHa, *dHb, *dT, *dA1, *dagg, *dZemb, *dYz, *dA0, *dvn_a, *dvn_b, *dG1, *dG2, *dtmp, *poolG;
-  float *deps_part, *bag_scratch, *emb_scratch, *slabs, *bn_scratch, *col_stats;
+  float *deps_part, *bag_scratch, *emb_scratch, *emb_scratch_n, *slabs, *bn_scratch, *col_stats, *bn_scratch_e, *col_stats_e;
   int64_t total;
 };
 
@@ -810,6 +810,8 @@ static OgbLayout plan_layout_ogb(const esc_ogb_gnn_t* m, int64_t N, int64_t E, i
   y.pooled = a.take(G * H); y.logits = a.take(G * T); y.dlogits = a.take(G * T);
   y.bn_scratch = a.take(esc_bn_scratch(H2));
   y.col_stats = a.take(2 * ((E > N ? E : N) / 32 + 1) * H2);
+  y.bn_scratch_e = a.take(esc_bn_scratch(H2));               // the edge pipeline's own BatchNorm scratch / GEMM-epilogue partials
+  y.col_stats_e = a.take(2 * (E / 32 + 1) * H2);
   if (train) {
     y.dTcat = a.take(rows_total * H);
     y.dpooled = a.take(G * H); y.dHa = a.take(N * H); y.dHb = a.take(N * H); y.dT = a.take(N * H);
@@ -822,6 +824,7 @@ static OgbLayout plan_layout_ogb(const esc_ogb_gnn_t* m, int64_t N, int64_t E, i
     y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
     const int64_t ent = atom_entries > bond_entries ? atom_entries : bond_entries;
     y.emb_scratch = a.take(esc_bag_bwd_scratch(ent, H));
+    y.emb_scratch_n = a.take(esc_bag_bwd_scratch(ent, H));
     int64_t sl = esc_linear_bwd_weight_scratch(E, H, H) + 64;                                   // zlin
     for (int l = 0; l < L; ++l) {
       sl += esc_linear_bwd_weight_scratch(E, H, H) + esc_linear_bwd_weight_scratch(N, H2, H) +
@@ -852,32 +855,53 @@ static int forward_ogb(const OgbCtx& z) {
   const Ctx& c = z.c;
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, G = y.G, T = y.T, H2 = 2 * H;
   const float p = z.p;
-  // encoders' tables in one buffer; h0 = AtomEncoder(x) (:264-282); vn_0 = virtualnode_embedding(0) per graph (:701)
+  // encoders' tables in one buffer (both pipelines read it)
   ESC_TRY(esc_table_pack(&m->tables, H, y.Tcat, c.s));
+  // ---- edge pipeline (second stream, like the counting engine): ESC bag, z_embedding, the edge terms of all layers
+  EdgeStream& es = edge_stream();
+  Ctx ce = c;
+  if (es.ok) {
+    ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));
+    ce = edge_ctx(c, es.stream);
+  }
+  // z_emb = z_embedding(ESC bag): Dropout BN ReLU Linear Dropout BN ReLU (:638-645)
+  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, ce.s));
+  if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, ce.s));
+  if (p > 0.f) ESC_TRY(esc_dropout_fwd(y.Zb, H, E, H, p, drop_seed(z, 0), nullptr, 0, y.Zd, H, y.mask_z0, ce.s));
+  ESC_TRY(bn_coeffs(ce, y.Zd, H, E, m->zbn0, y.zb0));
+  ESC_TRY(esc_affine_act(y.Zd, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, ce.s));
+  if (p > 0.f) {
+    ESC_TRY(esc_linear_fwd(y.A0, H, m->zlin.w, H, m->zlin.b, nullptr, nullptr, E, H, H, y.Yz, H, nullptr, ce.s));
+    ESC_TRY(esc_dropout_fwd(y.Yz, H, E, H, p, drop_seed(z, 1), nullptr, 0, y.Yzd, H, y.mask_z1, ce.s));
+    ESC_TRY(bn_coeffs(ce, y.Yzd, H, E, m->zbn1, y.zb1));
+  } else {
+    ESC_TRY(linear_bn(ce, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
+  }
+  ESC_TRY(esc_affine_act(y.Yzd, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, ce.s));
+  // edge term of layer l = BondEncoder(edge_attr) + edge_encoder_pos(z_emb) (:352)
+  auto edge_term = [&](int l) -> int {
+    const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
+    const esc_ogb_layer_t& q = m->layer[l];
+    ESC_TRY(esc_linear_fwd(y.Zemb, H, q.pos.w, H, q.pos.b, nullptr, nullptr, E, H, H, y.l[l].e, H, nullptr, ce.s));
+    ESC_TRY(esc_bag_fwd_acc(y.Tcat + q.bond_row0 * H, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, y.l[l].e, H, ce.s));
+    if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_ogb: stream event failed"); return ESC_ELAUNCH; }
+    return ESC_OK;
+  };
+  const int ahead = es.ok ? g_edge_ahead : (int)L;
+  for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
+  // ---- node pipeline: h0 = AtomEncoder(x) (:264-282); vn_0 = virtualnode_embedding(0) per graph (:701)
   ESC_TRY(esc_bag_fwd(y.Tcat, H, b->atoms.row_ptr, b->atoms.idx, b->atoms.ones, N, y.h0, H, c.s));
   ESC_TRY(esc_embed_fwd(m->vn_w, 1, H, b->zero_idx, G, y.l[0].vn, H, nullptr, c.s));
-  // z_emb = z_embedding(ESC bag): Dropout BN ReLU Linear Dropout BN ReLU (:638-645)
-  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, c.s));
-  if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, c.s));
-  if (p > 0.f) ESC_TRY(esc_dropout_fwd(y.Zb, H, E, H, p, drop_seed(z, 0), nullptr, 0, y.Zd, H, y.mask_z0, c.s));
-  ESC_TRY(bn_coeffs(c, y.Zd, H, E, m->zbn0, y.zb0));
-  ESC_TRY(esc_affine_act(y.Zd, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, c.s));
-  if (p > 0.f) {
-    ESC_TRY(esc_linear_fwd(y.A0, H, m->zlin.w, H, m->zlin.b, nullptr, nullptr, E, H, H, y.Yz, H, nullptr, c.s));
-    ESC_TRY(esc_dropout_fwd(y.Yz, H, E, H, p, drop_seed(z, 1), nullptr, 0, y.Yzd, H, y.mask_z1, c.s));
-    ESC_TRY(bn_coeffs(c, y.Yzd, H, E, m->zbn1, y.zb1));
-  } else {
-    ESC_TRY(linear_bn(c, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
-  }
-  ESC_TRY(esc_affine_act(y.Yzd, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, c.s));
   for (int l = 0; l < (int)L; ++l) {
     const esc_ogb_layer_t& q = m->layer[l];
     const OgbLayer& w = y.l[l];
-    ESC_TRY(esc_segment_broadcast_add(y.h[l], H, w.vn, H, b->graph_ptr, G, N, H, w.hin, H, c.s));                    // :739
-    // edge term = BondEncoder(edge_attr) + edge_encoder_pos(z_emb) (:352)
-    ESC_TRY(esc_linear_fwd(y.Zemb, H, q.pos.w, H, q.pos.b, nullptr, nullptr, E, H, H, w.e, H, nullptr, c.s));
-    ESC_TRY(esc_bag_fwd_acc(y.Tcat + q.bond_row0 * H, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, w.e, H, c.s));
+    ESC_TRY(esc_segment_broadcast_add(y.h[l], H, w.vn, H, b->graph_ptr, G, N, H, w.hin, H, c.s));                 // :739
+    if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_ogb: stream event failed"); return ESC_ELAUNCH; }
     ESC_TRY(esc_gine_aggregate_fwd(w.hin, H, w.e, H, b->in_ptr, b->in_edge, b->in_src, q.eps, N, H, w.agg, H, c.s));
+    if (es.ok && l + ahead < (int)L) {
+      ESC_TRY(chain(es.agg_done[l], (hipStream_t)c.s, es.stream));
+      ESC_TRY(edge_term(l + ahead));
+    }
     ESC_TRY(linear_bn(c, w.agg, H, q.lin0, nullptr, nullptr, N, w.Y0, q.bn0, w.b0));
     ESC_TRY(esc_affine_act(w.Y0, H2, N, H2, w.b0.scale, w.b0.shift, 1, w.A1, H2, c.s));
     ESC_TRY(linear_bn(c, w.A1, H2, q.lin1, nullptr, nullptr, N, w.hc, q.bn, w.bn));                                // + batch_norms[l] statistics
@@ -894,7 +918,10 @@ static int forward_ogb(const OgbCtx& z) {
     }
   }
   ESC_TRY(esc_segment_pool_fwd(y.hL, H, b->graph_ptr, G, H, m->mean_pool, y.pooled, H, c.s));
-  return esc_linear_fwd(y.pooled, H, m->head.w, H, m->head.b, nullptr, nullptr, G, T, H, y.logits, T, nullptr, c.s);
+  ESC_TRY(esc_linear_fwd(y.pooled, H, m->head.w, H, m->head.b, nullptr, nullptr, G, T, H, y.logits, T, nullptr, c.s));
+  // a forward-only call (predict / forward_train) returns with the caller's stream ordered behind the edge stream too
+  if (es.ok) ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));
+  return ESC_OK;
 }
 
 static int backward_ogb(const OgbCtx& z) {
@@ -912,6 +939,13 @@ static int backward_ogb(const OgbCtx& z) {
   float* dvn_next = nullptr;                     // d vn_{l+1}
   float* dvn_cur = y.dvn_a;
   std::vector<esc_sum_job> eps_jobs;
+  // the edge pipeline's backward (bond tables, edge_encoder_pos, z_embedding, bag) runs on the second stream behind d_e[l]
+  EdgeStream& es = edge_stream();
+  Ctx ce = es.ok ? edge_ctx(c, es.stream) : c;
+  std::vector<esc_reduce_job> edge_jobs;
+  edge_jobs.reserve(ESC_MAX_REDUCE_JOBS);
+  if (es.ok && c.jobs) ce.jobs = &edge_jobs;
+  if (es.ok) ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));      // (a backward called on its own: order behind the caller's stream)
   for (int l = (int)L - 1; l >= 0; --l) {
     const esc_ogb_layer_t& q = m->layer[l];
     const OgbLayer& w = y.l[l];
@@ -943,10 +977,11 @@ static int backward_ogb(const OgbCtx& z) {
     ESC_TRY(esc_gine_aggregate_bwd(w.hin, H, w.e, H, y.dagg, H, b->out_ptr, b->out_edge, b->out_dst, q.eps, N, H, w.d_e, H,
                                    dHin, H, have_dhin ? 1 : 0, y.deps_part + (int64_t)l * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, q.deps});
-    // edge term: bond tables and edge_encoder_pos
+    // edge term: bond tables and edge_encoder_pos — edge stream
+    if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));
     ESC_TRY(esc_bag_bwd_table(w.d_e, H, H, b->bonds.col_ptr, b->bonds.c_row, b->bonds.ones, b->bonds.c_col, b->bonds.n_entries,
-                              m->bond_rows, y.dTcat + q.bond_row0 * H, y.emb_scratch, c.s));
-    ESC_TRY(linear_backward(c, w.d_e, H, y.Zemb, H, nullptr, nullptr, q.pos, E, y.dZemb, H, last ? 0 : 1));
+                              m->bond_rows, y.dTcat + q.bond_row0 * H, y.emb_scratch, ce.s));
+    ESC_TRY(linear_backward(ce, w.d_e, H, y.Zemb, H, nullptr, nullptr, q.pos, E, y.dZemb, H, last ? 0 : 1));
     // d hin_l is complete: d h_l = d hin_l, d vn_l += add_pool(d hin_l)
     ESC_TRY(esc_segment_pool_fwd(dHin, H, b->graph_ptr, G, H, 0, y.poolG, H, c.s));
     ESC_TRY(esc_dropout_bwd(y.poolG, H, G, H, 0.f, nullptr, last ? nullptr : dvn_cur, H, dvn_cur, H, c.s));
@@ -956,20 +991,22 @@ static int backward_ogb(const OgbCtx& z) {
   }
   // encoders
   ESC_TRY(esc_bag_bwd_table(dH, H, H, b->atoms.col_ptr, b->atoms.c_row, b->atoms.ones, b->atoms.c_col, b->atoms.n_entries,
-                            m->atom_rows, y.dTcat, y.emb_scratch, c.s));
+                            m->atom_rows, y.dTcat, y.emb_scratch_n, c.s));
   ESC_TRY(esc_embed_bwd(dvn_next, H, b->zero_idx, G, 1, H, m->vn_dw, c.s));
-  ESC_TRY(esc_table_unpack_grad(&m->tables, H, y.dTcat, c.s));
-  // z_embedding + bag
-  ESC_TRY(bn_backward(c, y.Yzd, H, y.Zemb, H, y.dZemb, H, E, y.zb1, m->zbn1, y.dYz, H, y.bn_scratch));
-  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dYz, H, E, H, p, y.mask_z1, nullptr, 0, y.dYz, H, c.s));
-  ESC_TRY(linear_backward(c, y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dA0, H, 0));
-  ESC_TRY(bn_backward(c, y.Zd, H, y.A0, H, y.dA0, H, E, y.zb0, m->zbn0, y.dA0, H, y.bn_scratch));
-  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dA0, H, E, H, p, y.mask_z0, nullptr, 0, y.dA0, H, c.s));
+  // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order)
+  ESC_TRY(bn_backward(ce, y.Yzd, H, y.Zemb, H, y.dZemb, H, E, y.zb1, m->zbn1, y.dYz, H, ce.y.bn_scratch));
+  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dYz, H, E, H, p, y.mask_z1, nullptr, 0, y.dYz, H, ce.s));
+  ESC_TRY(linear_backward(ce, y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dA0, H, 0));
+  ESC_TRY(bn_backward(ce, y.Zd, H, y.A0, H, y.dA0, H, E, y.zb0, m->zbn0, y.dA0, H, ce.y.bn_scratch));
+  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dA0, H, E, H, p, y.mask_z0, nullptr, 0, y.dA0, H, ce.s));
   ESC_TRY(esc_bag_bwd_table_rows(y.dA0, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
-                                 m->dz_table, y.bag_scratch, c.s));
+                                 m->dz_table, y.bag_scratch, ce.s));
+  if (es.ok && !edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));
+  // node-side reductions overlap the edge tail; then join and hand the packed table gradients back to the tables
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
-  return ESC_OK;
+  if (es.ok) ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));
+  return esc_table_unpack_grad(&m->tables, H, y.dTcat, c.s);
 }
 
 static int check_ogb(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, const float* ws, bool train, bool need_y) {
@@ -993,6 +1030,7 @@ static OgbCtx make_ogb(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* 
            Ctx{nullptr, nullptr, Layout{}, stream, train}, train ? m->drop_ratio : 0.f};
   z.c.y.H = m->hidden; z.c.y.N = b->N; z.c.y.E = b->E;
   z.c.y.col_stats = z.o.col_stats; z.c.y.bn_scratch = z.o.bn_scratch; z.c.y.slabs = z.o.slabs;
+  z.c.y.col_stats_e = z.o.col_stats_e; z.c.y.bn_scratch_e = z.o.bn_scratch_e;
   z.c.act = 1;
   return z;
 }
@@ -1187,6 +1225,7 @@ static int copy_floats(float* dst, const float* src, int64_t n, void* stream, co
 
 int esc_zinc_train_step(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, int64_t loss_denom,
                         float* loss, float* pred, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_zinc(m, b, workspace, true, true);
   if (rc) return rc;
   ESC_REQUIRE(loss, "esc_zinc_train_step: null loss pointer");
@@ -1202,6 +1241,7 @@ int esc_zinc_train_step(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float
 }
 
 int esc_zinc_forward_train(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, float* pred, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_zinc(m, b, workspace, true, false);
   if (rc) return rc;
   ESC_REQUIRE(pred, "esc_zinc_forward_train: null output");
@@ -1214,6 +1254,7 @@ int esc_zinc_forward_train(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, fl
 }
 
 int esc_zinc_backward(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, const float* dpred, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_zinc(m, b, workspace, true, false);
   if (rc) return rc;
   ESC_REQUIRE(dpred, "esc_zinc_backward: null gradient");
@@ -1227,6 +1268,7 @@ int esc_zinc_backward(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* 
 }
 
 int esc_zinc_predict(const esc_zinc_gin_t* m, const esc_mol_batch_t* b, float* workspace, float* pred, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_zinc(m, b, workspace, false, false);
   if (rc) return rc;
   ESC_REQUIRE(pred, "esc_zinc_predict: null output");
@@ -1250,6 +1292,7 @@ static void ogb_jobs(OgbCtx& z, std::vector<esc_reduce_job>& jobs, float*& curso
 
 int esc_ogb_train_step(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, int64_t loss_denom, float* loss,
                        float* logits, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_ogb(m, b, workspace, true, true);
   if (rc) return rc;
   ESC_REQUIRE(loss, "esc_ogb_train_step: null loss pointer");
@@ -1264,6 +1307,7 @@ int esc_ogb_train_step(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* 
 }
 
 int esc_ogb_forward_train(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, float* logits, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_ogb(m, b, workspace, true, false);
   if (rc) return rc;
   ESC_REQUIRE(logits, "esc_ogb_forward_train: null output");
@@ -1276,6 +1320,7 @@ int esc_ogb_forward_train(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, floa
 }
 
 int esc_ogb_backward(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, const float* dlogits, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_ogb(m, b, workspace, true, false);
   if (rc) return rc;
   ESC_REQUIRE(dlogits, "esc_ogb_backward: null gradient");
@@ -1288,6 +1333,7 @@ int esc_ogb_backward(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* wo
 }
 
 int esc_ogb_predict(const esc_ogb_gnn_t* m, const esc_ogb_batch_t* b, float* workspace, float* logits, void* stream) {
+  ESC_TRY(finish_pending(pending()));
   int rc = check_ogb(m, b, workspace, false, false);
   if (rc) return rc;
   ESC_REQUIRE(logits, "esc_ogb_predict: null output");

@@ -930,6 +930,9 @@ static int g_use_dma = 15;        // bit 0: forward, bit 1: gradients, bit 2: th
 static inline bool dma_ok(const void* p, int64_t rows, int64_t ld) {
   return aligned16(p) && ld % 4 == 0 && rows * ld * 4 < (1LL << 31);
 }
+// a 128-wide tile dimension over `dim` columns: acceptable when the padding to a multiple of 128 wastes <= 10 % of the MFMA
+// work (256, 600 -> yes; 300 -> 384 is 28 % waste -> 64-wide tiles: 320)
+static inline bool tile128_ok(int64_t dim) { return cdiv(dim, 128) * 128 * 10 <= dim * 11; }
 static inline hipError_t dma_check(hipError_t e, const char* what) {
   if (e != hipSuccess) set_error("%s: %s", what, hipGetErrorString(e));
   return e;
@@ -959,8 +962,9 @@ static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, 
   if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
     e = dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
   } else if (M >= 8192 && N >= 128) {     // edge-sized: 128x128 tile, 4 compute + 4 loader waves, one workgroup per CU
-    e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s)
-                 : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
+    if (in_scale)               e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s);
+    else if (tile128_ok(N))     e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
+    else                        e = dma::launch_gemm<128, 64, 32, 2, 2, 3, 2, false, false, 0, true, false>(g, 0, s);   // N = 300: 5 x 64 instead of 3 x 128
   } else {                         // node-sized: 64x64 tile, 4 compute + 2 loader waves
     e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 1, true, false>(g, 0, s)
                  : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 0, true, false>(g, 0, s);
@@ -1180,7 +1184,7 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
   if (dma_bwd_ok(dY, ld_dy, nullptr, 0, W, ld_w, M, N, K, dX, ld_dx, nullptr, true, false)) {
     dma::GArgs d{};
     dma_fill_dx(d, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
-    const hipError_t e = M >= 8192 ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s)
+    const hipError_t e = (M >= 8192 && tile128_ok(K)) ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s)
                                    : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, true, 0, false, false>(d, 0, s);
     return dma_check(e, "esc_linear_bwd_input") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
   }
@@ -1269,7 +1273,7 @@ static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t l
     return ESC_OK;
   }
   if (dma_bwd_ok(dY, ld_dy, X, ld_x, nullptr, 0, M, N, K, nullptr, 0, slabs, false, true)) {
-    const bool big = M >= 8192;
+    const bool big = M >= 8192 && tile128_ok(N) && tile128_ok(K);
     dma_wgrad_plan(M, N, K, big ? 128 : 64, big ? 128 : 64, &splits, &per);
     dma::GArgs d{};
     dma_fill_dw(d, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
@@ -1405,7 +1409,7 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
       dma_bwd_ok(dY, ld_dy, X, ld_x, W, ld_w, M, N, K, dX, ld_dx, slabs, true, true)) {
     // dX tiles + split-M dW slabs of the LDS-DMA family in ONE launch
     hipStream_t s = (hipStream_t)stream;
-    const bool big = M >= 8192;
+    const bool big = M >= 8192 && tile128_ok(N) && tile128_ok(K);
     int splits, per;
     dma_wgrad_plan(M, N, K, big ? 128 : 64, big ? 128 : 64, &splits, &per);
     dma::DualArgs a{};
