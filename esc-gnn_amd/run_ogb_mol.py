@@ -131,10 +131,20 @@ def main(argv=None):
                   adj_dropout=args.adj_dropout, subgraph_pooling=args.subgraph_pooling, graph_pooling=args.graph_pooling)
 
     def train(model, optimizer, gen):
+        from .engine import OgbStepEngine, ogb_engine_ready, ogb_engine_supports
         model.train()
+        engine = model.__dict__.get("_esc_step_engine")
+        if engine is None and ogb_engine_supports(model):
+            engine = model.__dict__["_esc_step_engine"] = OgbStepEngine(model)    # forward + masked BCE + backward in ONE call
+        if engine is not None:
+            engine.refresh()                                # (the optimiser owns the gradient buffers: re-read the addresses)
         total = torch.zeros((), device=ctx.device)
         for data, _ in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
             y = data.y.view(-1, num_tasks)
+            if engine is not None and ctx.world == 1 and ogb_engine_ready(model, data):
+                total += engine.train_step(data) * y.shape[0]
+                optimizer.step()
+                continue
             optimizer.zero_grad()
             pred = model(data)
             loss = ops.bce_with_logits_loss(pred, y)      # NaN (unlabelled) targets ignored, reference :65-70

@@ -123,10 +123,22 @@ def main(argv=None):
                                   min_lr=0.00001)
     gen = torch.Generator().manual_seed(args.seed)
 
+    from .engine import ZincStepEngine, zinc_engine_ready, zinc_engine_supports
+    engine = ZincStepEngine(model) if zinc_engine_supports(model) else None     # forward + L1 + backward in ONE call
+
     def train(epoch):
         model.train()
         loss_all = torch.zeros((), device=ctx.device)
         for data, n_global in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
+            if engine is not None and zinc_engine_ready(model, data):           # (a 1-graph tail batch takes the per-op path)
+                n_loc = data.y.numel()
+                if ctx.world > 1:                          # sums, one all-reduce of grad ++ [n_local], division inside Adam
+                    loss_all += engine.train_step(data, loss_denom=1)
+                    optimizer.step(grad_denom=optimizer.all_reduce_sum(n_loc))
+                else:
+                    loss_all += engine.train_step(data) * n_loc
+                    optimizer.step()
+                continue
             optimizer.zero_grad()
             y = data.y.view(-1, 1)
             if ctx.world > 1 and args.sync_bn:            # one objective shared by the ranks: sum form, divided once
