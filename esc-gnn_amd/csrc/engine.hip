@@ -14,6 +14,7 @@
 // use_cycle=True — the configuration run_graphcount.py:465 instantiates).
 #include "common.h"
 
+#include <map>
 #include <vector>
 #include <cstdlib>
 
@@ -169,10 +170,16 @@ struct EdgeStream {
 };
 static int g_edge_priority_low = 1;
 static int g_use_edge_stream = 1;     // esc_engine_set_side_stream() bit 1
+static int current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
 static EdgeStream& edge_stream() {
-  static thread_local EdgeStream es;
+  static thread_local std::map<int, EdgeStream> per_device;   // streams / events belong to the device that was current when they were made
   static thread_local EdgeStream off;   // ok == false
   if (!g_use_edge_stream) return off;
+  EdgeStream& es = per_device[current_device()];
   if (!es.ok && es.stream == nullptr) {
     // lowest priority: when workgroup slots free up, the latency-critical node chain is served first
     int least = 0, greatest = 0;
@@ -191,6 +198,14 @@ static EdgeStream& edge_stream() {
   }
   return es;
 }
+// The molecule engines use the second stream only when the batch has enough edges for the edge-sized kernels to matter:
+// ZINC at bs=128 (6 400 edges) measured 1.24 ms on one stream and 1.35 ms on two (the events cost more than the overlap
+// returns); ogbg-molhiv at bs=256 (20 000 edges, emb 300) 5.44 -> 5.18 ms.
+static int64_t g_two_stream_min_edges = 12000;       // esc_engine_set_two_stream_min_edges()
+static EdgeStream& edge_stream_for(int64_t edges) {
+  static thread_local EdgeStream off;   // ok == false
+  return edges >= g_two_stream_min_edges ? edge_stream() : off;
+}
 // `waiter` continues only after everything queued on `src` so far
 static int chain(hipEvent_t ev, hipStream_t src, hipStream_t waiter) {
   if (hipEventRecord(ev, src) != hipSuccess || hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) {
@@ -201,9 +216,10 @@ static int chain(hipEvent_t ev, hipStream_t src, hipStream_t waiter) {
 }
 
 static SideStream& side_stream() {
-  static thread_local SideStream ss;
+  static thread_local std::map<int, SideStream> per_device;
   static thread_local SideStream off;   // ok == false
   if (!g_use_side_stream) return off;
+  SideStream& ss = per_device[current_device()];
   if (!ss.ok && ss.stream == nullptr) {
     bool good = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess;
     hipEvent_t* evs[4] = {&ss.fork_f, &ss.join_f, &ss.fork_b, &ss.join_b};
@@ -631,6 +647,8 @@ static Layout plan_layout_zinc(const esc_zinc_gin_t* m, int64_t N, int64_t E, in
   y.bn_scratch = a.take(esc_bn_scratch(H));
   y.col_stats = a.take(2 * ((E > N ? E : N) / 32 + 1) * H);
   y.col_stats_b = a.take(2 * (N / 32 + 1) * H);
+  y.bn_scratch_e = a.take(esc_bn_scratch(H));
+  y.col_stats_e = a.take(2 * (E / 32 + 1) * H);
   if (train) {
     y.dcat = a.take(N * y.W); y.dpool = a.take(G * y.W); y.dAl = a.take(G * H);
     y.dT1 = a.take(N * H); y.dT2 = a.take(N * H); y.dagg = a.take(N * H); y.dX0 = a.take(N * C0);
@@ -664,32 +682,55 @@ static int forward_zinc(const ZincCtx& z) {
   const Layout& y = c.y;
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W, G = y.G, D = y.D, Wz = y.Wz, C0 = y.C0;
   const int act = c.act;
-  // x = node_type_embedding(data.x) (:581)
-  ESC_TRY(esc_embed_fwd(m->node_emb.w, m->node_emb.rows, C0, b->node_type, N, y.X0, C0, nullptr, c.s));
+  // ---- edge pipeline on the second stream (as in the counting engine): bag, z_embedding, edge-term input, edge terms
+  EdgeStream& es = edge_stream_for(E);
+  Ctx ce = c;
+  if (es.ok) {
+    ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));
+    ce = edge_ctx(c, es.stream);
+  }
   // z_emb = z_embedding(ESC bag) (:589-590), written into the first H columns of the edge-term input; the last D
   // columns are edge_type_embedding(edge_attr) (:591)
-  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, c.s));
-  if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, c.s));
-  ESC_TRY(bn_coeffs(c, y.Zb, H, E, m->zbn0, y.zb0));
-  ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, act, y.A0, H, c.s));
-  ESC_TRY(linear_bn(c, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
-  ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, act, y.Zcat, Wz, c.s));
-  ESC_TRY(esc_embed_fwd(m->edge_emb.w, m->edge_emb.rows, D, b->edge_type, E, y.Zcat + H, Wz, nullptr, c.s));
+  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, ce.s));
+  if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, ce.s));
+  ESC_TRY(bn_coeffs(ce, y.Zb, H, E, m->zbn0, y.zb0));
+  ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, act, y.A0, H, ce.s));
+  ESC_TRY(linear_bn(ce, y.A0, H, m->zlin, nullptr, nullptr, E, y.Yz, m->zbn1, y.zb1));
+  ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, act, y.Zcat, Wz, ce.s));
+  ESC_TRY(esc_embed_fwd(m->edge_emb.w, m->edge_emb.rows, D, b->edge_type, E, y.Zcat + H, Wz, nullptr, ce.s));
+  auto edge_term = [&](int l) -> int {
+    const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
+    const esc_conv_t& cv = m->conv[l];
+    const int64_t C = l == 0 ? C0 : H;
+    ESC_TRY(esc_linear_fwd(y.Zcat, Wz, cv.lin.w, Wz, cv.lin.b, nullptr, nullptr, E, C, Wz, y.e[l], C, nullptr, ce.s));
+    if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_zinc: stream event failed"); return ESC_ELAUNCH; }
+    return ESC_OK;
+  };
+  const int ahead = es.ok ? g_edge_ahead : (int)L;
+  for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
+  // ---- node pipeline: x = node_type_embedding(data.x) (:581)
+  ESC_TRY(esc_embed_fwd(m->node_emb.w, m->node_emb.rows, C0, b->node_type, N, y.X0, C0, nullptr, c.s));
   // GINE layers (:593-598): xs[l] -> cat[:, l*H : (l+1)*H]
   for (int l = 0; l < (int)L; ++l) {
     const esc_conv_t& cv = m->conv[l];
     const int64_t C = l == 0 ? C0 : H;
     const float* hin = l == 0 ? y.X0 : y.cat + (int64_t)(l - 1) * H;
     const int64_t ld_h = l == 0 ? C0 : W;
-    ESC_TRY(esc_linear_fwd(y.Zcat, Wz, cv.lin.w, Wz, cv.lin.b, nullptr, nullptr, E, C, Wz, y.e[l], C, nullptr, c.s));
+    if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_zinc: stream event failed"); return ESC_ELAUNCH; }
     ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    if (es.ok && l + ahead < (int)L) {
+      ESC_TRY(chain(es.agg_done[l], (hipStream_t)c.s, es.stream));
+      ESC_TRY(edge_term(l + ahead));
+    }
     ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)l * H, W));
   }
   // readout (:601-609): global_add_pool -> lin1 -> bn_lin1 -> ELU -> lin2
   ESC_TRY(esc_segment_pool_fwd(y.cat, W, b->graph_ptr, G, W, 0, y.pooled, W, c.s));
   ESC_TRY(linear_bn(c, y.pooled, W, m->lin1, nullptr, nullptr, G, y.Yl, m->bn_lin1, y.bl));
   ESC_TRY(esc_affine_act(y.Yl, H, G, H, y.bl.scale, y.bl.shift, act, y.Al, H, c.s));
-  return esc_linear_fwd(y.Al, H, m->lin2.w, H, m->lin2.b, nullptr, nullptr, G, 1, H, y.pred, 1, nullptr, c.s);
+  ESC_TRY(esc_linear_fwd(y.Al, H, m->lin2.w, H, m->lin2.b, nullptr, nullptr, G, 1, H, y.pred, 1, nullptr, c.s));
+  if (es.ok) ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));    // forward-only calls return ordered behind the edge stream
+  return ESC_OK;
 }
 
 static int backward_zinc(const ZincCtx& z) {
@@ -698,6 +739,12 @@ static int backward_zinc(const ZincCtx& z) {
   const Ctx& c = z.c;
   const Layout& y = c.y;
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W, G = y.G, D = y.D, Wz = y.Wz, C0 = y.C0;
+  EdgeStream& es = edge_stream_for(E);
+  Ctx ce = es.ok ? edge_ctx(c, es.stream) : c;
+  std::vector<esc_reduce_job> edge_jobs;
+  edge_jobs.reserve(ESC_MAX_REDUCE_JOBS);
+  if (es.ok && c.jobs) ce.jobs = &edge_jobs;
+  if (es.ok) ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));
   ESC_TRY(linear_backward(c, y.dpred, 1, y.Al, H, nullptr, nullptr, m->lin2, G, y.dAl, H, 0));
   ESC_TRY(bn_backward(c, y.Yl, H, y.Al, H, y.dAl, H, G, y.bl, m->bn_lin1, y.dAl, H, y.bn_scratch));
   ESC_TRY(linear_backward(c, y.dAl, H, y.pooled, W, nullptr, nullptr, m->lin1, G, y.dpool, W, 0));
@@ -713,18 +760,21 @@ static int backward_zinc(const ZincCtx& z) {
     ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
                                    y.d_e[l], C, dx, l == 0 ? C0 : W, l == 0 ? 0 : 1, y.deps_part + (int64_t)l * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
-    ESC_TRY(linear_backward(c, y.d_e[l], C, y.Zcat, Wz, nullptr, nullptr, cv.lin, E, y.dZcat, Wz, l == (int)L - 1 ? 0 : 1));
+    if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));      // conv.lin backward: edge stream
+    ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Zcat, Wz, nullptr, nullptr, cv.lin, E, y.dZcat, Wz, l == (int)L - 1 ? 0 : 1));
   }
   ESC_TRY(esc_embed_bwd(y.dX0, C0, b->node_type, N, m->node_emb.rows, C0, m->node_emb.dw, c.s));
-  ESC_TRY(esc_embed_bwd(y.dZcat + H, Wz, b->edge_type, E, m->edge_emb.rows, D, m->edge_emb.dw, c.s));
-  // z_embedding + bag
-  ESC_TRY(bn_backward(c, y.Yz, H, y.Zcat, Wz, y.dZcat, Wz, E, y.zb1, m->zbn1, y.dZemb, H, y.bn_scratch));
-  ESC_TRY(linear_backward(c, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
-  ESC_TRY(bn_backward(c, y.Zb, H, y.A0, H, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, y.bn_scratch));
+  // edge pipeline tail: edge-type table, z_embedding, bag
+  ESC_TRY(esc_embed_bwd(y.dZcat + H, Wz, b->edge_type, E, m->edge_emb.rows, D, m->edge_emb.dw, ce.s));
+  ESC_TRY(bn_backward(ce, y.Yz, H, y.Zcat, Wz, y.dZcat, Wz, E, y.zb1, m->zbn1, y.dZemb, H, ce.y.bn_scratch));
+  ESC_TRY(linear_backward(ce, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
+  ESC_TRY(bn_backward(ce, y.Zb, H, y.A0, H, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, ce.y.bn_scratch));
   ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
-                                 m->dz_table, y.bag_scratch, c.s));
+                                 m->dz_table, y.bag_scratch, ce.s));
+  if (es.ok && !edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
+  if (es.ok) ESC_TRY(chain(es.joined, es.stream, (hipStream_t)c.s));
   return ESC_OK;
 }
 
@@ -858,7 +908,7 @@ static int forward_ogb(const OgbCtx& z) {
   // encoders' tables in one buffer (both pipelines read it)
   ESC_TRY(esc_table_pack(&m->tables, H, y.Tcat, c.s));
   // ---- edge pipeline (second stream, like the counting engine): ESC bag, z_embedding, the edge terms of all layers
-  EdgeStream& es = edge_stream();
+  EdgeStream& es = edge_stream_for(E);
   Ctx ce = c;
   if (es.ok) {
     ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));
@@ -940,7 +990,7 @@ static int backward_ogb(const OgbCtx& z) {
   float* dvn_cur = y.dvn_a;
   std::vector<esc_sum_job> eps_jobs;
   // the edge pipeline's backward (bond tables, edge_encoder_pos, z_embedding, bag) runs on the second stream behind d_e[l]
-  EdgeStream& es = edge_stream();
+  EdgeStream& es = edge_stream_for(E);
   Ctx ce = es.ok ? edge_ctx(c, es.stream) : c;
   std::vector<esc_reduce_job> edge_jobs;
   edge_jobs.reserve(ESC_MAX_REDUCE_JOBS);
@@ -1050,6 +1100,11 @@ static int check(const esc_nested_gin_t* m, const esc_batch_t* b, const float* w
 using namespace esc;
 
 extern "C" {
+
+int esc_engine_set_two_stream_min_edges(int64_t edges) {
+  g_two_stream_min_edges = edges < 0 ? 0 : edges;
+  return ESC_OK;
+}
 
 int esc_engine_set_side_stream(int on) {
   g_use_edge_stream = (on & 2) != 0;

@@ -141,9 +141,16 @@ def main(argv=None):
         total = torch.zeros((), device=ctx.device)
         for data, _ in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
             y = data.y.view(-1, num_tasks)
-            if engine is not None and ctx.world == 1 and ogb_engine_ready(model, data):
-                total += engine.train_step(data) * y.shape[0]
-                optimizer.step()
+            if engine is not None and ogb_engine_ready(model, data):
+                if ctx.world > 1:                           # sum-form gradients, ONE all-reduce of grad ++ [labeled targets]
+                    n_lab = int((y == y).sum())
+                    loss_sum = engine.train_step(data, loss_denom=1)
+                    denom = optimizer.all_reduce_sum(n_lab)
+                    optimizer.step(grad_denom=denom)
+                    total += loss_sum / max(n_lab, 1) * y.shape[0]
+                else:
+                    total += engine.train_step(data) * y.shape[0]
+                    optimizer.step()
                 continue
             optimizer.zero_grad()
             pred = model(data)

@@ -319,6 +319,8 @@ typedef struct esc_batch_t {
  * bit 1 (default on): the edge-sized conv.lin GEMMs of all layers run on a second HIP stream, ordered against the
  * node chain by one event per dependency; bit 0 (default off): the x_embedding branch on a further stream.  Default 2. */
 int esc_engine_set_side_stream(int on);
+/* esc_zinc_* / esc_ogb_*: smallest batch (in edges) whose edge pipeline runs on the second stream (default 12 000; 0 = always) */
+int esc_engine_set_two_stream_min_edges(int64_t edges);
 /* 1 (default): write relu(BN(.)) of the two EDGE-sized z_embedding activations once instead of re-applying the
  * affine+ReLU prologue in every consumer GEMM; 0: fully fused (less memory, slower on MI355X r01). */
 int esc_engine_set_materialise_edge_act(int on);
@@ -372,7 +374,9 @@ int esc_engine_predict(const esc_nested_gin_t* m, const esc_batch_t* b, float* w
  * readout global_add_pool(cat(xs)) -> lin1 -> BatchNorm -> ELU -> lin2 (:601-609), L1 loss over the graphs (run_zinc.py).
  * Same conventions as esc_engine_*: gradients are WRITTEN into the d* slots; the batch needs >= 2 graphs
  * (the reference skips bn_lin1 for a single graph, :603-604 — that case stays on the per-op path).
- * Activations are materialised (the GEMM prologue of the counting engine is ReLU-only); one stream. */
+ * Activations are materialised (the GEMM prologue of the counting engine is ReLU-only); the edge pipeline (bag, z_embedding,
+ * edge terms and their backward) runs on the engine's second stream like the counting model's when the batch has >= 12 000
+ * edges (below that one stream is faster). */
 typedef struct esc_embed_t { const float* w; float* dw; int64_t rows, dim; } esc_embed_t;
 typedef struct esc_zinc_gin_t {
   int64_t num_layers, hidden, z_rows;
@@ -431,7 +435,7 @@ int esc_bag_fwd_acc(const float* table, int64_t H, const int32_t* row_ptr, const
  * residual (:744-752), virtual-node update add_pool(h)+vn -> MLP -> dropout (:757-783); JK = last; sum / mean graph
  * pooling + graph_pred_linear (:66-261); BCE-with-logits over the labeled targets (run_ogb_mol.py:65-72).
  * z_embedding = Dropout BN ReLU Linear Dropout BN ReLU (:638-645).  Dropout uses esc_dropout_fwd's own random stream.
- * One stream; gradients are WRITTEN into the d* slots; needs >= 2 graphs. */
+ * Two streams (edge pipeline on the engine's second stream, batches of >= 12 000 edges); gradients are WRITTEN into the d* slots; needs >= 2 graphs. */
 typedef struct esc_ogb_layer_t {
   const float* eps; float* deps;
   esc_linear_t pos;                                        /* convs[l].edge_encoder_pos */

@@ -391,7 +391,18 @@ def test_gineplus_against_reference_class_golden(which):
         _close(p.grad, torch.tensor(g["%s_grad_%s" % (which, n)]), "%s grad %s" % (which, n), tol=2e-5)
 
 
-def test_zinc_step_engine_train_step_and_predict():
+@pytest.fixture(params=[12000, 0], ids=["one_stream", "two_streams"])
+def mol_streams(request):
+    """the molecule engines put their edge pipeline on a second stream for batches of >= 12 000 edges; 0 forces it for the
+    small fixtures"""
+    require_gpu()
+    from esc_gnn_amd import _native as nv
+    nv.call("esc_engine_set_two_stream_min_edges", request.param)
+    yield request.param
+    nv.call("esc_engine_set_two_stream_min_edges", 12000)
+
+
+def test_zinc_step_engine_train_step_and_predict(mol_streams):
     """ZincStepEngine.train_step (forward + L1 + backward in one call) and .predict against the per-op path of the same
     module: loss, predictions, every gradient, BatchNorm running statistics; eval-mode predictions."""
     require_gpu()
@@ -444,7 +455,7 @@ def _engine_uniform01(seed, n):
 
 
 @pytest.mark.parametrize("p,residual,pooling", [(0.0, True, "mean"), (0.5, True, "mean"), (0.3, False, "sum")])
-def test_ogb_step_engine_matches_per_op_path(p, residual, pooling):
+def test_ogb_step_engine_matches_per_op_path(p, residual, pooling, mol_streams):
     """OgbStepEngine.train_step / .predict against the per-op path of the same module — including DROPOUT: the engine
     draws its masks from a counter-based hash; the test regenerates exactly those masks on the host and makes the per-op
     path apply them (z_embedding's Dropout modules and the F.dropout calls of the node / virtual-node updates, in the
