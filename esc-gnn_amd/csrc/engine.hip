@@ -269,7 +269,7 @@ static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's
 // bit 2 / ESC_BN_FOLD=1).  Measured on MI355X (cfg1, untraced, same box): 1.154 ms with it vs 1.144 ms without — with the
 // host running ahead a finalize launch costs the node chain ~5 us, and so does the redundant merge in every consumer
 // workgroup (77 KB of partials + 38 fp64 merges: GEMM 8.5 -> 13.3 us, affine pass 4.4 -> 10 us).  Off by default.
-static int g_fold = getenv("ESC_BN_FOLD") ? 1 : 0;
+static int g_fold = getenv("ESC_BN_FOLD") ? atoi(getenv("ESC_BN_FOLD")) : 0;     // 1: both BatchNorms of an MLP merged by their consumers; 2: only the last one (by the affine pass)
 
 static esc_bn_fold make_fold(const float* partials, int64_t rows, int64_t block_rows, int64_t C, const esc_bn_t& bn, const BnWs& w) {
   return esc_bn_fold{partials, rows, block_rows, C, bn.eps, bn.momentum, bn.gamma, bn.beta, w.mean, w.invstd, w.scale, w.shift,
@@ -370,6 +370,12 @@ static bool fold_ok(const Ctx& c, int64_t M) {
 static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
                        float* out, int64_t ld_out) {
   const int64_t H = c.y.H;
+  if (fold_ok(c, M) && g_fold == 2) {         // only the MLP's last BatchNorm: its finalize launch folds into the affine pass
+    ESC_TRY(linear_bn(c, A, ld_a, p.lin0, nullptr, nullptr, M, w.Y0, p.bn0, w.b0));
+    ESC_TRY(esc_linear_fwd(w.Y0, H, p.lin1.w, H, p.lin1.b, w.b0.scale, w.b0.shift, M, H, H, w.Y1, H, c.y.col_stats_b, c.s));
+    const esc_bn_fold f1 = make_fold(c.y.col_stats_b, M, esc_linear_stats_block_rows(w.Y0, H, p.lin1.w, H, M, H, H), H, p.bn1, w.b1);
+    return esc_affine_act_fold(w.Y1, H, M, H, &f1, 1, out, ld_out, c.s);
+  }
   if (fold_ok(c, M)) {
     const int64_t K0 = p.lin0.in_dim;
     ESC_TRY(esc_linear_fwd(A, ld_a, p.lin0.w, K0, p.lin0.b, nullptr, nullptr, M, H, K0, w.Y0, H, c.y.col_stats, c.s));
@@ -1156,7 +1162,7 @@ int esc_engine_set_collective(esc_allreduce_fn fn, void* user, int rank, int wor
 
 int esc_engine_set_gemm_stats(int on) {
   g_fuse_finalize = (on & 2) == 0;       // bit 1: keep the statistics epilogue but finalize in a separate launch
-  g_fold = (on & 4) != 0;                // bit 2: node-sized BatchNorms are merged by their consumers (see g_fold)
+  g_fold = (on & 8) ? 2 : ((on & 4) != 0);   // bit 2: node-sized BatchNorms are merged by their consumers; bit 3: only an MLP's last one
   g_gemm_stats = (on & 1) != 0;
   return ESC_OK;
 }
