@@ -95,6 +95,44 @@ class DeviceGraphStore(object):
                 if torch.is_tensor(v) or k in self._META}
         torch.save(blob, path)
 
+    # ---- the reference's own processed layout: InMemoryDataset's `(data, slices)` (GraphCountDataset.py:119-120) -------
+    def to_data_slices(self):
+        """-> (data, slices): per-key concatenation of all graphs (graph-LOCAL node ids in edge_index, graph-local edge ids
+        in pos_batch, exactly what InMemoryDataset.collate stores) and the per-key slice offsets, as plain dicts of CPU
+        tensors — `torch.save((data, slices), path)` writes a file that loads with weights_only=True and, under PyG, is
+        what `Data.from_dict(data)` / the dataset's `slices` expect."""
+        x = self.x_all.cpu()
+        x = (x.long().view(-1) if self.x_was_1d else x.long()) if self.x_is_int else x
+        y = self.y_all.cpu()
+        data = dict(x=x, edge_index=torch.stack([self.esrc_all, self.edst_all]).cpu(),
+                    y=y.view(-1) if (self.y_is_vector and self.y_dim == 1) else y,
+                    pos_enc=self.pos_enc_all.cpu(), pos_index=self.pos_index_all.cpu(), pos_batch=self.pos_batch_all.cpu())
+        slices = dict(x=self.h_node_ptr.clone(), edge_index=self.h_edge_ptr.clone(), y=self.h_y_ptr.clone(),
+                      pos_enc=self.h_nnz_ptr.clone(), pos_index=self.h_nnz_ptr.clone(), pos_batch=self.h_nnz_ptr.clone())
+        if self.edge_attr_all is not None:
+            data["edge_attr"], slices["edge_attr"] = self.edge_attr_all.cpu(), self.h_edge_ptr.clone()
+        return data, slices
+
+    @classmethod
+    def from_data_slices(cls, data, slices, device):
+        """Build the store from the reference's `(data, slices)` pair: `data` is a mapping or any object with the keys as
+        attributes (a PyG `Data` loaded by the user's own torch_geometric), `slices` maps each key to its G+1 offsets."""
+        from .data import Data
+        get = (lambda k: data[k] if k in data else None) if isinstance(data, dict) else (lambda k: getattr(data, k, None))
+        keys = [k for k in ("x", "edge_index", "edge_attr", "y", "pos_enc", "pos_index", "pos_batch") if get(k) is not None]
+        for k in ("x", "edge_index", "y", "pos_enc", "pos_index", "pos_batch"):
+            if k not in keys or k not in slices:
+                raise KeyError("from_data_slices: key %r missing from data / slices" % k)
+        G = int(slices["x"].numel()) - 1
+        graphs = []
+        for g in range(G):
+            kw = {}
+            for k in keys:
+                t, a, b = get(k), int(slices[k][g]), int(slices[k][g + 1])
+                kw[k] = t[:, a:b] if k == "edge_index" else t[a:b]
+            graphs.append(Data(**kw))
+        return cls(graphs, device)
+
     @classmethod
     def load(cls, path, device):
         dev = torch.device(device)

@@ -129,3 +129,27 @@ def test_plan_cache_follows_the_index_tensors(E):
     assert p3 is not p2
     src = data.edge_index[0][p3.out_edge.long()]
     assert bool((src[1:] >= src[:-1]).all())
+
+
+def test_reference_data_slices_layout_round_trip(E, tmp_path):
+    """the reference's InMemoryDataset cache is `torch.save((data, slices), path)` (GraphCountDataset.py:119-120): the
+    store writes that layout as plain tensors (loadable with weights_only=True), reads it back — from a dict or from an
+    object with attributes, as a PyG Data would be — and collates the same batches."""
+    import os
+    import types
+    store, datas, ref, _ = _store(E, "mixed4")
+    data, slices = store.to_data_slices()
+    assert data["edge_index"].shape[0] == 2 and int(slices["x"][-1]) == data["x"].size(0)
+    for g, d in enumerate(datas):                                   # per-graph pieces are the original graphs
+        a, b = int(slices["edge_index"][g]), int(slices["edge_index"][g + 1])
+        assert torch.equal(data["edge_index"][:, a:b], d.edge_index)
+        za, zb = int(slices["pos_batch"][g]), int(slices["pos_batch"][g + 1])
+        assert torch.equal(data["pos_batch"][za:zb], d.pos_batch)
+    path = os.path.join(tmp_path, "data_tr.pt")
+    torch.save((data, slices), path)
+    d2, s2 = torch.load(path, weights_only=True)
+    for src in (d2, types.SimpleNamespace(**d2)):
+        again = E.DeviceGraphStore.from_data_slices(src, s2, "cuda:0")
+        a, b = store.collate([0, 1, 2, 3]), again.collate([0, 1, 2, 3])
+        for k in a.keys:
+            assert torch.equal(a[k], b[k]), k
