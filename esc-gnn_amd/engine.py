@@ -297,6 +297,22 @@ class _NodeCache(object):
         np.frombuffer(d, dtype=np.uint64)[self.slots] = np.uint64(grad_base) + self.byte_offsets
         return d
 
+    def descriptor_at(self, addresses):
+        """descriptor whose gradient slot of parameter i is addresses[i] (a FlatAdam bucket's own layout)"""
+        import numpy as np
+        d = getattr(self, "_struct", _Model).from_buffer_copy(self.template)
+        np.frombuffer(d, dtype=np.uint64)[self.slots] = np.asarray(addresses, dtype=np.uint64)[self.slot_param]
+        return d
+
+    def direct_bucket(self):
+        """the FlatAdam / FlatBucket that owns every parameter's .grad and is still clean (see
+        FlatBucket.direct_grad_addresses), as a list of gradient addresses — or None"""
+        from .parallel import _BUCKETS
+        g0 = self.params[0].grad
+        base = getattr(g0, "_base", None) if g0 is not None else None
+        bucket = _BUCKETS.get(base.data_ptr()) if base is not None else None
+        return bucket.direct_grad_addresses(self.params) if bucket is not None else None
+
 
 def _node_cache(model):
     c = model.__dict__.get("_esc_node_cache")
@@ -330,10 +346,16 @@ class _EngineNode(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
         cache = ctx.cache
-        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
-        desc = cache.descriptor(flat.data_ptr())
         g = dpred.reshape(-1)
         g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        direct = cache.direct_bucket()
+        if direct is not None:             # every .grad is a clean FlatAdam bucket view: write there, nothing to accumulate
+            desc = cache.descriptor_at(direct)
+            nv.call("esc_engine_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+            ctx.ws = ctx.keep = None
+            return (None, None, None) + (None,) * len(cache.params)
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
+        desc = cache.descriptor(flat.data_ptr())
         nv.call("esc_engine_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
         grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
                       for p, o in zip(cache.params, cache.offsets))
@@ -498,10 +520,16 @@ class _ZincEngineNode(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
         cache = ctx.cache
-        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)
-        desc = cache.descriptor(flat.data_ptr())
         g = dpred.reshape(-1)
         g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        direct = cache.direct_bucket()
+        if direct is not None:             # every .grad is a clean FlatAdam bucket view: write there, nothing to accumulate
+            desc = cache.descriptor_at(direct)
+            nv.call("esc_zinc_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+            ctx.ws = ctx.keep = None
+            return (None, None, None) + (None,) * len(cache.params)
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
+        desc = cache.descriptor(flat.data_ptr())
         nv.call("esc_zinc_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
         grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
                       for p, o in zip(cache.params, cache.offsets))
@@ -737,10 +765,16 @@ class _OgbEngineNode(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
         cache = ctx.cache
-        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)
-        desc = cache.descriptor(flat.data_ptr())
         g = dpred.reshape(-1)
         g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        direct = cache.direct_bucket()
+        if direct is not None:             # every .grad is a clean FlatAdam bucket view: write there, nothing to accumulate
+            desc = cache.descriptor_at(direct)
+            nv.call("esc_ogb_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+            ctx.ws = ctx.keep = None
+            return (None, None, None) + (None,) * len(cache.params)
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
+        desc = cache.descriptor(flat.data_ptr())
         nv.call("esc_ogb_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
         grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
                       for p, o in zip(cache.params, cache.offsets))

@@ -14,8 +14,12 @@ sum_r sum_i |err| / N_global — no second collective for the denominator.
 BatchNorm uses each shard's own batch statistics (plain DP).  Matching the single-device statistics
 would need a (sum, sumsq, count) all-reduce per BN layer (SyncBN) — not enabled in this revision.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
+
+_BUCKETS = weakref.WeakValueDictionary()      # gradient-store address -> FlatBucket (engine.py: direct gradient writes)
 
 
 def shard_slice(batch_size, rank, world):
@@ -64,13 +68,35 @@ class FlatBucket(object):
             self.flat_param[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + k].view(p.shape)
             p.grad = self.flat_grad[off:off + k].view(p.shape)
+        self._offset_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+        self.engine_direct = True          # the whole-step engines may write a backward's gradients straight into the bucket
+        self._clean_version = None         # version of the gradient store right after zero_grad(): nobody has written since
+        _BUCKETS[self._grad_store.data_ptr()] = self
 
     def zero_grad(self, set_to_none=False):
         self._grad_store.zero_()
+        base = self.flat_grad.data_ptr()
         for p, off in zip(self.params, self.offsets):      # autograd may have replaced .grad: re-bind the views
-            k = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad[off:off + k].data_ptr():
-                p.grad = self.flat_grad[off:off + k].view(p.shape)
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+        self._clean_version = self._grad_store._version
+
+    def direct_grad_addresses(self, params):
+        """Addresses of the gradient slots of `params` inside this bucket IF a backward may write them directly: the bucket
+        is still exactly as zero_grad() left it (no accumulation has touched it — torch's version counter of the store
+        is unchanged — and no engine has written into it), and every parameter's .grad is this bucket's view.  Writing
+        into zeros equals accumulating into them, later AccumulateGrad nodes add on top as usual.  None otherwise."""
+        if not self.engine_direct or self._clean_version is None or self._clean_version != self._grad_store._version:
+            return None
+        base, out = self.flat_grad.data_ptr(), []
+        for p in params:
+            off = self._offset_of.get(id(p))
+            if off is None or p.grad is None or p.grad.data_ptr() != base + 4 * off or not p.requires_grad:
+                return None
+            out.append(base + 4 * off)
+        self._clean_version = None                         # (the raw write does not move torch's version counter)
+        return out
 
     def all_reduce_weighted(self, n_local, group=None):
         """grad <- sum_r n_r * grad_r / sum_r n_r   with one SUM all-reduce."""

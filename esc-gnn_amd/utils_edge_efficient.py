@@ -122,13 +122,23 @@ def create_subgraphs(data, h=1, sample_ratio=1.0, max_nodes_per_hop=None, node_l
     return _rebuild(data, enc, self_loop)
 
 
-def create_subgraphs_many(data_list, h=1, use_rd=False, self_loop=False, chunk=4096):
-    """Encode many graphs with a handful of launches (chunked to bound device scratch)."""
+def create_subgraphs_many(data_list, h=1, use_rd=False, self_loop=False, chunk=4096, table_budget=1 << 30):
+    """Encode many graphs with a handful of launches.  A chunk ends after `chunk` graphs or when the per-root hop tables
+    of its graphs (sum of n^2 bytes) would exceed `table_budget` — device scratch stays bounded for datasets of large
+    graphs too."""
     h_last = _check_args(h, None, None)
-    out = []
-    for i in range(0, len(data_list), chunk):
-        part = data_list[i:i + chunk]
+    out, i = [], 0
+    while i < len(data_list):
+        j, sq = i, 0
+        while j < len(data_list) and j - i < chunk:
+            n = _num_nodes(data_list[j])
+            if j > i and sq + n * n > table_budget:
+                break
+            sq += n * n
+            j += 1
+        part = data_list[i:j]
         encs = encode_edge_lists([_num_nodes(d) for d in part], [d.edge_index.cpu() for d in part], h_last,
                                  use_rd, self_loop)
         out.extend(_rebuild(d, e, self_loop) for d, e in zip(part, encs))
+        i = j
     return out

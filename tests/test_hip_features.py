@@ -137,3 +137,16 @@ def test_ego_nets_beyond_lds_with_rd(E, case):
         want = orc.encode_graph(s, t, n, h, True, sl)
         _cmp(enc, dict(out_src=want["edge_src"], out_dst=want["edge_dst"], pos_enc=want["pos_enc"],
                        pos_index=want["pos_index"], pos_batch=want["pos_batch"]), "%s/%d" % (case, i))
+
+
+def test_many_graphs_chunking_by_hop_table_budget(E):
+    """create_subgraphs_many ends a chunk when the per-root hop tables (sum of n^2) would exceed the budget: same
+    result whatever the chunking"""
+    graphs = [gs.count_shape_graph(g) for g in range(60, 72)] + [gs.molecule_like_graph(s) for s in range(70, 76)]
+    datas = [E.Data(x=torch.ones(n, 1), edge_index=torch.tensor(np.stack([s, t])), y=torch.zeros(1)) for n, s, t in graphs]
+    whole = E.create_subgraphs_many(datas, 3, use_rd=True, self_loop=True)
+    pieces = E.create_subgraphs_many(datas, 3, use_rd=True, self_loop=True, table_budget=900)     # ~1-2 graphs per chunk
+    tiny = E.create_subgraphs_many(datas, 3, use_rd=True, self_loop=True, chunk=5)
+    for a, b, c in zip(whole, pieces, tiny):
+        for k in ("edge_index", "pos_enc", "pos_index", "pos_batch"):
+            assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k

@@ -538,3 +538,53 @@ def test_ogb_step_engine_matches_per_op_path(p, residual, pooling, mol_streams):
     if p > 0:                                                            # a second step draws different masks
         l3 = eng.train_step(d2)
         assert float(l3) != float(loss2)
+
+
+def test_engine_node_writes_into_a_clean_flatadam_bucket():
+    """`model(batch)` as one autograd node + FlatAdam: when the optimiser's gradient bucket is exactly as zero_grad() left
+    it, the backward writes the gradients straight into it (no per-parameter AccumulateGrad adds); every other situation
+    — a second backward without zero_grad, another branch of the graph that also reaches a parameter — must give the
+    same gradients as autograd's own accumulation."""
+    require_gpu()
+    import copy
+    import esc_gnn_amd as E
+    torch.manual_seed(5)
+    _, b, _ = load_collate("count3")
+    bt = {k: torch.tensor(v) for k, v in b.items()}
+    m1 = E.NestedGIN_eff(None, 3, 64, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to("cuda:0").train()
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.startswith("x_embedding") and p.dim() == 2:
+                p.add_(0.3 * torch.randn_like(p))
+    m2 = copy.deepcopy(m1)
+    y = bt["y"].float().to("cuda:0")
+
+    def loss_of(m, data, extra):
+        out = m(data)
+        loss = E.ops.l1_loss(out, y)
+        return loss + 0.1 * m.lin2.weight.sum() + 0.05 * (m.z_initial.weight ** 2).sum() if extra else loss
+
+    for extra in (False, True):
+        # reference: plain .grad tensors managed by autograd (set_to_none -> the node's views are adopted, later adds are autograd's)
+        for p in m1.parameters():
+            p.grad = None
+        loss_of(m1, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
+        want = {n: p.grad.clone() for n, p in m1.named_parameters()}
+        opt = E.optim.FlatAdam(m2.parameters(), lr=1e-3) if not extra else opt      # noqa: F821  (same bucket both rounds)
+        opt.zero_grad()
+        loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
+        assert opt._clean_version is None                                   # the direct path was taken
+        for n, p in m2.named_parameters():
+            assert p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * opt._offset_of[id(p)], n
+            _close(p.grad, want[n].cpu(), "direct grad " + n, tol=2e-5)
+        # a second backward without zero_grad: gradients accumulate (the bucket is not clean any more)
+        loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
+        for n, p in m2.named_parameters():
+            _close(p.grad, 2 * want[n].cpu(), "accumulated grad " + n, tol=4e-5)
+        # engine_direct off: same numbers through AccumulateGrad
+        opt.engine_direct = False
+        opt.zero_grad()
+        loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
+        for n, p in m2.named_parameters():
+            _close(p.grad, want[n].cpu(), "accumulate-path grad " + n, tol=2e-5)
+        opt.engine_direct = True
