@@ -17,10 +17,11 @@ they are derived here by esc_plan_csr (csrc/plan.hip), once per batch and cached
 import torch
 
 
-def _csr(key, n_keys, want_perm=True):
+def _csr(key, n_keys, want_perm=True, bad=None):
     """stable grouping of positions 0..len(key)-1 by key -> (ptr int32[n_keys+1], perm int32 or None), on the device:
     esc_plan_csr (csrc/plan.hip: LSD radix passes of the positions + an integer histogram), no library sort.
-    Raises IndexError when a key lies outside [0, n_keys)."""
+    Raises IndexError when a key lies outside [0, n_keys) — or, when the caller passes `bad` (a 1-element int32 device
+    tensor), only sets it, so that several calls can share ONE host read-back."""
     from . import _native as nv
     if key.device.type != "cuda":
         raise RuntimeError("esc_gnn_amd: execution plans are built on the GPU (got a %s tensor) - move the batch to the "
@@ -32,9 +33,11 @@ def _csr(key, n_keys, want_perm=True):
     ptr = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(n, dtype=torch.int32, device=dev) if want_perm else None
     scratch = torch.empty(nv.lib().esc_plan_csr_scratch(n, n_keys), dtype=torch.int32, device=dev)
-    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    deferred = bad is not None
+    if not deferred:
+        bad = torch.empty(1, dtype=torch.int32, device=dev)
     nv.call("esc_plan_csr", nv.ptr(key), n, n_keys, nv.ptr(ptr), nv.ptr(perm), nv.ptr(scratch), nv.ptr(bad), nv.stream())
-    if int(bad.item()):
+    if not deferred and int(bad.item()):
         raise IndexError("plan: a key lies outside [0, %d)" % n_keys)
     return ptr, perm
 
@@ -65,27 +68,31 @@ class BatchPlan(object):
     def from_tensors(edge_index, num_nodes, pos_enc=None, pos_index=None, pos_batch=None, n_cols=1800):
         src, dst = edge_index[0], edge_index[1]
         E = src.numel()
-        in_ptr, in_edge = _csr(dst, num_nodes)
-        out_ptr, out_edge = _csr(src, num_nodes)
+        flags = torch.zeros(5, dtype=torch.int32, device=src.device)      # one host read-back for all the range checks
+        in_ptr, in_edge = _csr(dst, num_nodes, bad=flags[0:1])
+        out_ptr, out_edge = _csr(src, num_nodes, bad=flags[1:2])
         kw = dict(in_ptr=in_ptr, in_edge=in_edge, in_src=src[in_edge.long()].to(torch.int32),
                   out_ptr=out_ptr, out_edge=out_edge, out_dst=dst[out_edge.long()].to(torch.int32),
                   num_nodes=int(num_nodes), num_edges=int(E), nnz=0, n_cols=n_cols)
         if pos_batch is not None:
             Z = pos_batch.numel()
-            if Z and not bool((pos_batch[1:] >= pos_batch[:-1]).all()):
-                raise ValueError("pos_batch must be non-decreasing (as create_subgraphs emits it)")
-            try:
-                row_ptr, _ = _csr(pos_batch, E, want_perm=False)        # already grouped by edge: pointers only
-            except IndexError:
-                raise ValueError("pos_batch refers to an edge beyond the batch's %d edges" % E)
-            try:
-                col_ptr, col_perm = _csr(pos_index, n_cols)
-            except IndexError:
-                raise IndexError("pos_index outside the %d-row z_initial table" % n_cols)
+            if Z > 1:
+                flags[4:5] = (pos_batch[1:] < pos_batch[:-1]).any().to(torch.int32)
+            row_ptr, _ = _csr(pos_batch, E, want_perm=False, bad=flags[2:3])        # already grouped by edge: pointers only
+            col_ptr, col_perm = _csr(pos_index, n_cols, bad=flags[3:4])
             cp = col_perm.long()
             kw.update(row_ptr=row_ptr, bag_idx=pos_index.to(torch.int32), bag_val=pos_enc.to(torch.int32),
                       col_ptr=col_ptr, col_row=pos_batch[cp].to(torch.int32),
                       col_val=pos_enc[cp].to(torch.int32), col_col=pos_index[cp].to(torch.int32), nnz=int(Z))
+        f = flags.tolist()
+        if f[0] or f[1]:
+            raise IndexError("plan: edge_index refers to a node outside [0, %d)" % num_nodes)
+        if f[4]:
+            raise ValueError("pos_batch must be non-decreasing (as create_subgraphs emits it)")
+        if f[2]:
+            raise ValueError("pos_batch refers to an edge beyond the batch's %d edges" % E)
+        if f[3]:
+            raise IndexError("pos_index outside the %d-row z_initial table" % n_cols)
         return BatchPlan(**kw)
 
 

@@ -193,6 +193,15 @@ def test_bad_arguments_raise(E):
     with pytest.raises(IndexError):
         E.BatchPlan.from_tensors(b["edge_index"].to(dev), b["x"].shape[0], b["pos_enc"].to(dev),
                                  (b["pos_index"] + 1800).to(dev), b["pos_batch"].to(dev))
+    with pytest.raises(IndexError):                       # an edge endpoint beyond the node count
+        E.BatchPlan.from_tensors(b["edge_index"].to(dev), b["x"].shape[0] - 1, b["pos_enc"].to(dev), b["pos_index"].to(dev),
+                                 b["pos_batch"].to(dev))
+    with pytest.raises(ValueError):                       # a bag entry for an edge that does not exist
+        E.BatchPlan.from_tensors(b["edge_index"].to(dev), b["x"].shape[0], b["pos_enc"].to(dev), b["pos_index"].to(dev),
+                                 (b["pos_batch"] + 1).to(dev))
+    with pytest.raises(ValueError):                       # unsorted bag
+        E.BatchPlan.from_tensors(b["edge_index"].to(dev), b["x"].shape[0], b["pos_enc"].to(dev), b["pos_index"].to(dev),
+                                 b["pos_batch"].flip(0).to(dev))
 
 
 @pytest.mark.parametrize("C,mean", [(256, False), (1280, True), (10, True)])
