@@ -44,6 +44,8 @@ def parse():
                     help="weak (default): --batch_size graphs per GPU and step; strong: ONE global batch of --batch_size graphs "
                          "per step, sliced by graph over the ranks (SURVEY 8e)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="esc_tune_set(knob, value), repeatable")
+    ap.add_argument("--node_priority", type=int, default=0,
+                    help="-1: run the step (the node pipeline) on a HIGH-priority HIP stream instead of torch's default stream")
     ap.add_argument("--streams", type=int, default=None,
                     help="esc_engine_set_side_stream mode (default: the library's; 0 = everything on one stream)")
     ap.add_argument("--path", choices=("engine", "autograd"), default="engine",
@@ -78,6 +80,8 @@ def main():
     local = local % torch.cuda.device_count()             # rehearsals may put several ranks on one card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.node_priority < 0:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     if world > 1:                                         # RCCL over xGMI; ESC_DIST_BACKEND=gloo only for rehearsing on one GPU
         backend = os.environ.get("ESC_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))

@@ -105,6 +105,8 @@ SIGNATURES = {
     "esc_collate_cols": [P, I64, P, I64, P, P, P, P],
     "esc_collate_fill": [POINTER(CollateArgs), P],
     "esc_engine_set_two_stream_min_edges": [I64],
+    "esc_gine_aggregate_fwd_affine": [P, I64, P, P, P, I64, P, P, P, P, I64, I64, P, I64, P],
+    "esc_gine_aggregate_bwd_affine": [P, I64, P, P, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P],
     "esc_embed_fwd": [P, I64, I64, P, I64, P, I64, P, P],
     "esc_embed_bwd": [P, I64, P, I64, I64, I64, P, P],
     "esc_zinc_workspace_floats": [P, I64, I64, I64, I64],

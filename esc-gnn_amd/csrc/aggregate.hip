@@ -32,14 +32,18 @@ namespace esc {
 // graphs) costs ONE round of memory latency instead of one per leftover edge.
 constexpr int AGG_BATCH = 8;
 
-template <int VEC>
+// AFF: x holds PRE-activation rows of a BatchNorm(+ReLU) whose output was never materialised; every row read applies
+// relu(x*xa_scale + xa_shift) on the fly (same fmaf + max as esc_affine_act, so the sums are bit-identical to the
+// materialised path) — the step engine's node chain loses one elementwise launch per layer.
+template <int VEC, bool AFF = false>
 __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x, int64_t ld_x,
                                                     const float* __restrict__ e, int64_t ld_e,
                                                     const int* __restrict__ in_ptr,
                                                     const int* __restrict__ in_edge,
                                                     const int* __restrict__ in_src,
                                                     const float* __restrict__ eps_p, int N, int C,
-                                                    float* __restrict__ out, int64_t ld_out) {
+                                                    float* __restrict__ out, int64_t ld_out,
+                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift) {
   ESC_PRIO();
   const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   if (node >= N) return;
@@ -50,9 +54,13 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
   const bool has_e = e != nullptr;                  // nullptr: message = relu(x_j)
   const float one_eps = has_self ? __fadd_rn(1.0f, *eps_p) : 0.f;
   for (int c = lane * VEC; c < C; c += WAVE * VEC) {
-    float acc[VEC], self[VEC];
+    float acc[VEC], self[VEC], asc[VEC], ash[VEC];
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+    for (int t = 0; t < VEC; ++t) { acc[t] = 0.f; asc[t] = 1.f; ash[t] = 0.f; }
+    if constexpr (AFF) {
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) { asc[t] = xa_scale[c + t]; ash[t] = xa_shift[c + t]; }
+    }
     {
       const float* ps = x + (size_t)node * ld_x + c;
       if constexpr (VEC == 4) {
@@ -60,6 +68,10 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
         self[0] = a.x; self[1] = a.y; self[2] = a.z; self[3] = a.w;
       } else {
         self[0] = *ps;
+      }
+      if constexpr (AFF) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) self[t] = fmaxf(fmaf(self[t], asc[t], ash[t]), 0.f);
       }
     }
     for (int j = beg; j < end; j += AGG_BATCH) {
@@ -84,8 +96,10 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
       for (int u = 0; u < AGG_BATCH; ++u) {
         if (j + u < end) {                                  // wave-uniform: ascending-edge order is preserved
 #pragma unroll
-          for (int t = 0; t < VEC; ++t)
-            acc[t] = __fadd_rn(acc[t], fmaxf(has_e ? __fadd_rn(xv[u][t], ev[u][t]) : xv[u][t], 0.f));
+          for (int t = 0; t < VEC; ++t) {
+            const float xs = AFF ? fmaxf(fmaf(xv[u][t], asc[t], ash[t]), 0.f) : xv[u][t];
+            acc[t] = __fadd_rn(acc[t], fmaxf(has_e ? __fadd_rn(xs, ev[u][t]) : xs, 0.f));
+          }
         }
       }
     }
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256) void agg_fwd_elem(const float* __restrict__ x,
 
 // ---- backward: one wave per SOURCE node (out-CSR) -------------------------------------------------
 // each edge has exactly one source, so d_e[k] is written exactly once and dx[i] needs no atomics.
-template <int VEC>
+template <int VEC, bool AFF = false>
 __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x, int64_t ld_x,
                                                     const float* __restrict__ e, int64_t ld_e,
                                                     const float* __restrict__ g, int64_t ld_g,
@@ -133,7 +147,8 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
                                                     const float* __restrict__ eps_p, int N, int C,
                                                     float* __restrict__ d_e, int64_t ld_de,
                                                     float* __restrict__ dx, int64_t ld_dx, int accumulate_dx,
-                                                    float* __restrict__ deps_part) {
+                                                    float* __restrict__ deps_part,
+                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift) {
   ESC_PRIO();
   const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   if (node >= N) return;
@@ -155,6 +170,10 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
         gi[0] = b.x; gi[1] = b.y; gi[2] = b.z; gi[3] = b.w;
       } else {
         xi[0] = *px; gi[0] = *pg;
+      }
+      if constexpr (AFF) {                                  // x is the pre-activation row: the layer input is relu(x*scale+shift)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) xi[t] = fmaxf(fmaf(xi[t], xa_scale[c + t], xa_shift[c + t]), 0.f);
       }
     }
 #pragma unroll
@@ -341,9 +360,9 @@ int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t
                      esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(out);
     const int64_t blocks = esc::cdiv(N, 4);
     if (vec)
-      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr);
     else
-      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr);
   } else {
     const int64_t blocks = esc::cdiv(N * C, 256);
     esc::launch(-1, esc::agg_fwd_elem, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
@@ -370,10 +389,47 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                    (!d_e || esc::aligned16(d_e)) && (!dx || esc::aligned16(dx));
   const int64_t blocks = esc::cdiv(N, 4);
   if (vec)
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr);
   else
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd");
+  return ESC_OK;
+}
+
+// The same two passes with the layer input given as the PRE-activation rows of a BatchNorm+ReLU that was never written:
+// x' = relu(x*x_scale + x_shift) is applied to every row as it is read (forward: the gathered and the self rows; backward:
+// the own row, for the ReLU mask of x'+e and for deps).  dx stays the gradient with respect to x'.  Wide rows only.
+int esc_gine_aggregate_fwd_affine(const float* x, int64_t ld_x, const float* x_scale, const float* x_shift, const float* e,
+                                  int64_t ld_e, const int32_t* in_ptr, const int32_t* in_edge, const int32_t* in_src,
+                                  const float* eps, int64_t N, int64_t C, float* out, int64_t ld_out, void* stream) {
+  ESC_REQUIRE(x && x_scale && x_shift && in_ptr && out, "esc_gine_aggregate_fwd_affine: null pointer");
+  ESC_REQUIRE(N >= 0 && C >= 64 && C % 4 == 0 && ld_x >= C && ld_x % 4 == 0 && (!e || (ld_e >= C && ld_e % 4 == 0)) && ld_out >= C && ld_out % 4 == 0 &&
+              N < (1LL << 31) / 64, "esc_gine_aggregate_fwd_affine: needs C >= 64, C and the leading dimensions multiples of 4 (N=%ld C=%ld)", (long)N, (long)C);
+  ESC_REQUIRE(esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(out), "esc_gine_aggregate_fwd_affine: pointers must be 16-byte aligned");
+  if (N == 0) return ESC_OK;
+  ESC_REQUIRE(in_edge && in_src, "esc_gine_aggregate_fwd_affine: null edge arrays");
+  esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, in_ptr,
+              in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift);
+  ESC_CHECK_LAUNCH("esc_gine_aggregate_fwd_affine");
+  return ESC_OK;
+}
+
+int esc_gine_aggregate_bwd_affine(const float* x, int64_t ld_x, const float* x_scale, const float* x_shift, const float* e,
+                                  int64_t ld_e, const float* g, int64_t ld_g, const int32_t* out_ptr, const int32_t* out_edge,
+                                  const int32_t* out_dst, const float* eps, int64_t N, int64_t C, float* d_e, int64_t ld_de,
+                                  float* dx, int64_t ld_dx, int accumulate_dx, float* deps_part, void* stream) {
+  ESC_REQUIRE(x && x_scale && x_shift && g && out_ptr, "esc_gine_aggregate_bwd_affine: null pointer");
+  ESC_REQUIRE((e == nullptr) == (d_e == nullptr) || e != nullptr, "esc_gine_aggregate_bwd_affine: d_e without e");
+  ESC_REQUIRE(N >= 0 && C >= 64 && C % 4 == 0 && ld_x >= C && ld_x % 4 == 0 && (!e || (ld_e >= C && ld_e % 4 == 0)) && ld_g >= C && ld_g % 4 == 0 &&
+              (!d_e || (ld_de >= C && ld_de % 4 == 0)) && (!dx || (ld_dx >= C && ld_dx % 4 == 0)) && N < (1LL << 31) / 64,
+              "esc_gine_aggregate_bwd_affine: needs C >= 64, C and the leading dimensions multiples of 4");
+  ESC_REQUIRE(esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(g) && (!d_e || esc::aligned16(d_e)) && (!dx || esc::aligned16(dx)),
+              "esc_gine_aggregate_bwd_affine: pointers must be 16-byte aligned");
+  if (N == 0) return ESC_OK;
+  ESC_REQUIRE(out_edge && out_dst, "esc_gine_aggregate_bwd_affine: null edge arrays");
+  esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, g, ld_g,
+              out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift);
+  ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd_affine");
   return ESC_OK;
 }
 

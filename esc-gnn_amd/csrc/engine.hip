@@ -50,6 +50,7 @@ struct Layout {
   float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
   float *bn_scratch_e, *col_stats_e;   // the edge stream's own BatchNorm scratch / GEMM-epilogue partials
   // ZINC variant: node features from a table, [z_emb | edge type] edge-term input, pooled readout
+  float *cat_scale, *cat_shift;     // (scale, shift) of the BatchNorm that produced each H-wide slice of cat: [(L+1)*H]
   float *X0, *dX0, *Zcat, *dZcat, *pooled, *dpool, *Al;
   int64_t G, D, Wz;                 // graphs, type-embedding width, Wz = H + D
   int64_t total;
@@ -73,6 +74,11 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   }
   y.xemb.Y0 = a.take(N * H); y.xemb.Y1 = a.take(N * H); y.xemb.b0 = take_bn(a, H); y.xemb.b1 = take_bn(a, H);
   y.cat = a.take(N * y.W); y.Yl = a.take(N * H); y.bl = take_bn(a, H);
+  y.cat_scale = a.take(y.W); y.cat_shift = a.take(y.W);       // the slices' BatchNorm coefficients side by side (readout prologue)
+  if (base) {
+    y.xemb.b1.scale = y.cat_scale; y.xemb.b1.shift = y.cat_shift;
+    for (int l = 0; l < L; ++l) { y.conv[l].b1.scale = y.cat_scale + (int64_t)(l + 1) * H; y.conv[l].b1.shift = y.cat_shift + (int64_t)(l + 1) * H; }
+  }
   y.pred = a.take(N); y.dpred = a.take(N);
   y.bn_scratch = a.take(esc_bn_scratch(H));
   y.bn_scratch_x = a.take(esc_bn_scratch(H));
@@ -168,6 +174,7 @@ struct EdgeStream {
              agg_done[ESC_MAX_LAYERS] = {};
   bool ok = false;
 };
+static int g_split_last_lin = getenv("ESC_SPLIT_LAST_LIN") ? atoi(getenv("ESC_SPLIT_LAST_LIN")) : 1;   // see backward(): l == 0
 static int g_edge_priority_low = 1;
 static int g_use_edge_stream = 1;     // esc_engine_set_side_stream() bit 1
 static int current_device() {
@@ -269,7 +276,13 @@ static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's
 // bit 2 / ESC_BN_FOLD=1).  Measured on MI355X (cfg1, untraced, same box): 1.154 ms with it vs 1.144 ms without — with the
 // host running ahead a finalize launch costs the node chain ~5 us, and so does the redundant merge in every consumer
 // workgroup (77 KB of partials + 38 fp64 merges: GEMM 8.5 -> 13.3 us, affine pass 4.4 -> 10 us).  Off by default.
+// The LAST BatchNorm+ReLU of every node MLP is not materialised: the Linear writes its pre-BatchNorm rows straight into the
+// concat slice and the consumers apply relu(x*scale+shift) as they read them — the next layer's aggregate (forward and
+// backward, esc_gine_aggregate_*_affine) and the readout GEMM (prologue over all (L+1)*H columns).  One elementwise launch
+// less per layer on the dependent node chain.  ESC_FUSE_NODE_ACT=0 / esc_engine_set_gemm_stats bit 4 switch it off.
+static int g_fuse_node_act = getenv("ESC_FUSE_NODE_ACT") ? atoi(getenv("ESC_FUSE_NODE_ACT")) : 1;
 static int g_fold = getenv("ESC_BN_FOLD") ? atoi(getenv("ESC_BN_FOLD")) : 0;     // 1: both BatchNorms of an MLP merged by their consumers; 2: only the last one (by the affine pass)
+static bool fuse_node_act(const Ctx& c) { return g_fuse_node_act && !g_fold && c.act == 1 && c.y.H >= 64 && c.y.H % 4 == 0 && c.y.cat_scale != nullptr; }
 
 static esc_bn_fold make_fold(const float* partials, int64_t rows, int64_t block_rows, int64_t C, const esc_bn_t& bn, const BnWs& w) {
   return esc_bn_fold{partials, rows, block_rows, C, bn.eps, bn.momentum, bn.gamma, bn.beta, w.mean, w.invstd, w.scale, w.shift,
@@ -321,16 +334,17 @@ static int bn_backward(const Ctx& c, const float* X, int64_t ldx, const float* Y
 
 // Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
 static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linear_t& lin, const float* sc, const float* sh,
-                     int64_t M, float* Y, const esc_bn_t& bn, const BnWs& w) {
+                     int64_t M, float* Y, const esc_bn_t& bn, const BnWs& w, int64_t ld_y = 0) {
   const LdsFloorGuard cap(c.on_edge_stream && g_cap_forward);
   const int64_t H = lin.out_dim, K = lin.in_dim;          // (the BatchNorm is as wide as the Linear's output)
+  if (ld_y <= 0) ld_y = H;
   const bool sync = sync_on(c);     // statistics over all ranks: local ones first (no running update, no coefficients), then the exchange
   const bool fused = c.train && g_gemm_stats && H > 32 && c.jobs != nullptr;   // main chain only (col_stats is shared scratch)
   if (fused && g_fuse_finalize && M > 1 && !sync) {    // statistics AND their merge ride on the GEMM launch
     esc_bn_fuse f{bn.eps, bn.momentum, w.mean, w.invstd, bn.running_mean, bn.running_var, bn.gamma, bn.beta, w.scale, w.shift};
-    return esc_linear_bn_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, c.y.col_stats, &f, c.s);
+    return esc_linear_bn_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, ld_y, c.y.col_stats, &f, c.s);
   }
-  ESC_TRY(esc_linear_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, H, fused ? c.y.col_stats : nullptr, c.s));
+  ESC_TRY(esc_linear_fwd(X, ld_x, lin.w, K, lin.b, sc, sh, M, H, K, Y, ld_y, fused ? c.y.col_stats : nullptr, c.s));
   if (fused) {
     ESC_TRY(esc_bn_stats_from_partials_rows(c.y.col_stats, M, H, esc_linear_stats_block_rows(X, ld_x, lin.w, K, M, H, K), bn.eps,
                                             bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
@@ -339,7 +353,7 @@ static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linea
     return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
   }
   if (c.train) {
-    ESC_TRY(esc_bn_stats(Y, H, M, H, bn.eps, bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
+    ESC_TRY(esc_bn_stats(Y, ld_y, M, H, bn.eps, bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
                          sync ? nullptr : bn.running_var, bn.gamma, bn.beta, sync ? nullptr : w.scale, sync ? nullptr : w.shift,
                          c.y.bn_scratch, c.s));
     return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
@@ -368,8 +382,12 @@ static bool fold_ok(const Ctx& c, int64_t M) {
 }
 
 static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
-                       float* out, int64_t ld_out) {
+                       float* out, int64_t ld_out, bool pre_out = false) {
   const int64_t H = c.y.H;
+  if (pre_out) {                              // `out` receives the PRE-BatchNorm rows of lin1; w.b1 holds the coefficients
+    ESC_TRY(linear_bn(c, A, ld_a, p.lin0, nullptr, nullptr, M, w.Y0, p.bn0, w.b0));
+    return linear_bn(c, w.Y0, H, p.lin1, w.b0.scale, w.b0.shift, M, out, p.bn1, w.b1, ld_out);
+  }
   if (fold_ok(c, M) && g_fold == 2) {         // only the MLP's last BatchNorm: its finalize launch folds into the affine pass
     ESC_TRY(linear_bn(c, A, ld_a, p.lin0, nullptr, nullptr, M, w.Y0, p.bn0, w.b0));
     ESC_TRY(esc_linear_fwd(w.Y0, H, p.lin1.w, H, p.lin1.b, w.b0.scale, w.b0.shift, M, H, H, w.Y1, H, c.y.col_stats_b, c.s));
@@ -397,10 +415,11 @@ static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const f
 // given dOut (grad of the materialised output `out`), produce parameter grads and, if dA != NULL, dA
 static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
                         const float* out, int64_t ld_out, const float* dOut, int64_t ld_dout, float* dA,
-                        int64_t ld_da) {
+                        int64_t ld_da, bool pre_out = false) {
   const Layout& y = c.y;
   const int64_t H = y.H;
-  ESC_TRY(bn_backward(c, w.Y1, H, out, ld_out, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));
+  if (pre_out) ESC_TRY(bn_backward(c, out, ld_out, nullptr, 0, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));   // `out` = pre-BN rows
+  else         ESC_TRY(bn_backward(c, w.Y1, H, out, ld_out, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));
   if (w.A1) {
     ESC_TRY(linear_backward(c, y.dT1, H, w.A1, H, nullptr, nullptr, p.lin1, M, y.dT2, H, 0));
     ESC_TRY(bn_backward(c, w.Y0, H, w.A1, H, y.dT2, H, M, w.b0, p.bn0, y.dT2, H, y.bn_scratch));
@@ -461,10 +480,10 @@ static int forward(const Ctx& c) {
       return ESC_ELAUNCH;
     }
     const Ctx cx = side_ctx(c, ss.stream);
-    ESC_TRY(mlp_forward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W));
+    ESC_TRY(mlp_forward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, fuse_node_act(c)));
     (void)hipEventRecord(ss.join_f, ss.stream);
   } else {
-    ESC_TRY(mlp_forward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W));
+    ESC_TRY(mlp_forward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, fuse_node_act(c)));
   }
   // GINE layers (reference :161, :167-175): xs[l+1] -> cat[:, (l+1)H : (l+2)H]
   for (int l = 0; l < L; ++l) {
@@ -473,12 +492,16 @@ static int forward(const Ctx& c) {
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
     if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
-    ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    if (fuse_node_act(c) && l > 0)          // hin = pre-BatchNorm rows of the previous layer: relu(x*scale+shift) on the fly
+      ESC_TRY(esc_gine_aggregate_fwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], C, b->in_ptr,
+                                            b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    else
+      ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
     if (es.ok && l + ahead < (int)L) {
       ESC_TRY(chain(es.agg_done[l], (hipStream_t)c.s, es.stream));
       ESC_TRY(edge_term(l + ahead));
     }
-    ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W));
+    ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W, fuse_node_act(c)));
   }
   if (c.train) mark(PH_EDGE_FWD_DONE, ce.s);
   // readout (reference :183-189) needs every slice of cat, including the side stream's
@@ -491,7 +514,8 @@ static int forward(const Ctx& c) {
     const esc_bn_fold f = make_fold(c.y.col_stats, N, esc_linear_stats_block_rows(y.cat, W, m->lin1.w, W, N, H, W), H, m->bn_lin1, y.bl);
     return esc_linear_fwd_fold(y.Yl, H, m->lin2.w, H, m->lin2.b, &f, N, 1, H, y.pred, 1, nullptr, c.s);
   }
-  ESC_TRY(linear_bn(c, y.cat, W, m->lin1, nullptr, nullptr, N, y.Yl, m->bn_lin1, y.bl));
+  const bool fa = fuse_node_act(c);       // cat holds pre-BatchNorm rows: the readout GEMM applies every slice's BatchNorm+ReLU itself
+  ESC_TRY(linear_bn(c, y.cat, W, m->lin1, fa ? y.cat_scale : nullptr, fa ? y.cat_shift : nullptr, N, y.Yl, m->bn_lin1, y.bl));
   return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
 }
 
@@ -539,7 +563,8 @@ static int backward(const Ctx& c, Pending* defer) {
       float* slabs = *c.slab_cursor;
       *c.slab_cursor += (esc_linear_bwd_weight_scratch(N, H, ncols) + 63) & ~63LL;
       c.jobs->emplace_back();
-      return esc_linear_bwd_both_deferred(y.dAl, H, y.cat + col0, W, nullptr, nullptr, m->lin1.w + col0, W, N, H, ncols,
+      const bool fa = fuse_node_act(c);
+      return esc_linear_bwd_both_deferred(y.dAl, H, y.cat + col0, W, fa ? y.cat_scale + col0 : nullptr, fa ? y.cat_shift + col0 : nullptr, m->lin1.w + col0, W, N, H, ncols,
                                           y.dcat + col0, W, 0, m->lin1.dw + col0, W, db, slabs, &c.jobs->back(), stream);
     };
     ESC_TRY(chain(es.lin1_fork, (hipStream_t)c.s, es.stream));
@@ -550,7 +575,7 @@ static int backward(const Ctx& c, Pending* defer) {
     if (hipEventRecord(es.lin1_rest, es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     ESC_TRY(part(c.s, K0, H, m->lin1.db));
   } else {
-    ESC_TRY(linear_backward(c, y.dAl, H, y.cat, W, nullptr, nullptr, m->lin1, N, y.dcat, W, 0));
+    ESC_TRY(linear_backward(c, y.dAl, H, y.cat, W, fuse_node_act(c) ? y.cat_scale : nullptr, fuse_node_act(c) ? y.cat_shift : nullptr, m->lin1, N, y.dcat, W, 0));
   }
   // x_embedding backward (input x needs no gradient): only reads d(cat)[:, 0:H] -> side stream
   SideStream& ss = side_stream();
@@ -564,7 +589,7 @@ static int backward(const Ctx& c, Pending* defer) {
       return ESC_ELAUNCH;
     }
     const Ctx cx = side_ctx(c, ss.stream);
-    ESC_TRY(mlp_backward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
+    ESC_TRY(mlp_backward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0, fuse_node_act(c)));
     (void)hipEventRecord(ss.join_b, ss.stream);
   }
   // GINE layers, last to first (the eps gradients are only needed by the optimiser: one reduce launch at the end)
@@ -579,24 +604,43 @@ static int backward(const Ctx& c, Pending* defer) {
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
     ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W,
-                         y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C));
+                         y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C, fuse_node_act(c)));
     float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
     if (split_lin1 && l == (int)L - 1 &&                               // ... which the edge stream's lin1 blocks fill
         hipStreamWaitEvent((hipStream_t)c.s, es.lin1_rest, 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
-    ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
-                                   y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * N, c.s));
+    if (fuse_node_act(c) && l > 0)
+      ESC_TRY(esc_gine_aggregate_bwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], C, y.dagg, C,
+                                            b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C, y.d_e[l], C, dx, W, 1,
+                                            y.deps_part + (int64_t)l * N, c.s));
+    else
+      ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
+                                     y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));   // lin_l backward: edge stream
-    if (g_materialise_edge_act)
-      ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Zemb, H, nullptr, nullptr, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
-    else
-      ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Yz, H, y.zb1.scale, y.zb1.shift, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
+    const float* zin = g_materialise_edge_act ? y.Zemb : y.Yz;
+    const float* zsc = g_materialise_edge_act ? nullptr : y.zb1.scale;
+    const float* zsh = g_materialise_edge_act ? nullptr : y.zb1.shift;
+    if (l == 0 && es.ok && c.jobs && g_split_last_lin) {
+      // the LAST lin backward sits in the tail of the step: only its input gradient (which completes d(z_emb)) stays on
+      // the edge stream; the weight gradient runs on the node stream, which has nothing left to do
+      {
+        const LdsFloorGuard cap(true);
+        ESC_TRY(esc_linear_bwd_input(y.d_e[l], C, cv.lin.w, H, E, C, H, y.dZemb, H, l == (int)L - 1 ? 0 : 1, es.stream));
+      }
+      float* slabs = *c.slab_cursor;
+      *c.slab_cursor += (esc_linear_bwd_weight_scratch(E, C, H) + 63) & ~63LL;
+      c.jobs->emplace_back();
+      ESC_TRY(esc_linear_bwd_both_deferred(y.d_e[l], C, zin, H, zsc, zsh, cv.lin.w, H, E, C, H, nullptr, 0, 0, cv.lin.dw, H, cv.lin.db,
+                                           slabs, &c.jobs->back(), c.s));
+    } else {
+      ESC_TRY(linear_backward(ce, y.d_e[l], C, zin, H, zsc, zsh, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
+    }
     if (es.ok && !edge_jobs.empty()) {      // the edge stream now idles until d_e of the next layer: reduce these slabs there
       ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));
       edge_jobs.clear();
     }
   }
-  if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0));
+  if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0, fuse_node_act(c)));
   // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order); it overlaps the
   // x_embedding backward queued above on the node stream
   const bool mat = g_materialise_edge_act != 0;
@@ -1162,6 +1206,7 @@ int esc_engine_set_collective(esc_allreduce_fn fn, void* user, int rank, int wor
 
 int esc_engine_set_gemm_stats(int on) {
   g_fuse_finalize = (on & 2) == 0;       // bit 1: keep the statistics epilogue but finalize in a separate launch
+  g_fuse_node_act = (on & 16) == 0;      // bit 4: materialise the node MLPs' output activations again (one more launch per layer)
   g_fold = (on & 8) ? 2 : ((on & 4) != 0);   // bit 2: node-sized BatchNorms are merged by their consumers; bit 3: only an MLP's last one
   g_gemm_stats = (on & 1) != 0;
   return ESC_OK;

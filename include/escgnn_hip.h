@@ -82,6 +82,17 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                            int64_t ld_dx, int accumulate_dx /* dx += instead of = */, float* deps_part,
                            void* stream);
 
+/* esc_gine_aggregate_fwd / _bwd with the layer input given as PRE-activation rows of a BatchNorm+ReLU whose output is never
+ * written: x' = relu(x*x_scale + x_shift) is applied to every x row as it is read (the step engine's node chain saves one
+ * elementwise launch per layer); dx is the gradient with respect to x'.  C >= 64, multiples of 4, 16-byte aligned. */
+int esc_gine_aggregate_fwd_affine(const float* x, int64_t ld_x, const float* x_scale, const float* x_shift, const float* e,
+                                  int64_t ld_e, const int32_t* in_ptr, const int32_t* in_edge, const int32_t* in_src,
+                                  const float* eps, int64_t N, int64_t C, float* out, int64_t ld_out, void* stream);
+int esc_gine_aggregate_bwd_affine(const float* x, int64_t ld_x, const float* x_scale, const float* x_shift, const float* e,
+                                  int64_t ld_e, const float* g, int64_t ld_g, const int32_t* out_ptr, const int32_t* out_edge,
+                                  const int32_t* out_dst, const float* eps, int64_t N, int64_t C, float* d_e, int64_t ld_de,
+                                  float* dx, int64_t ld_dx, int accumulate_dx, float* deps_part, void* stream);
+
 /* graph readout (a-10): global_add_pool / global_mean_pool (run_graphcount.py:179; zinc_models.py:602) over the
  * sorted node->graph vector given as segment pointers seg_ptr[G+1]; rows summed in node order (bit-identical to
  * a sequential index_add_), mean divides by max(count,1).  Backward broadcasts g[graph]/count to the nodes. */
