@@ -596,68 +596,80 @@ struct ReduceJobs {
   unsigned char vec[ESC_MAX_REDUCE_JOBS];     // 1: four consecutive gradient elements per thread (float4 slab reads)
   int count;
 };
+// One workgroup owns 64 consecutive UNITS of a job (a unit = four consecutive gradient elements when the job allows float4
+// reads, one element otherwise; bias-gradient rows are further units); its four waves each add a quarter of the slabs
+// in split order — batches of 8 reads in flight, a short last batch padded by clamping the slab index and masking the
+// term, so that no wave ever walks a tail of dependent single loads — and wave 0 adds the four shares in wave order: a
+// fixed association, bitwise reproducible.  (One thread per unit walking all 60-75 slabs left the launch latency-bound:
+// 17 us for one edge-sized gradient, 20 us for the three 10-wide ones.)
+template <int VEC>
+__device__ __forceinline__ void slab_sum(const float* __restrict__ base, int64_t stride, int k0, int k1, int64_t off, bool live,
+                                         float (&s)[VEC]) {
+#pragma unroll
+  for (int t = 0; t < VEC; ++t) s[t] = 0.f;
+  if (!live) return;
+  for (int k = k0; k < k1; k += 8) {
+    float v[8][VEC];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = min(k + u, k1 - 1);
+      const float* p = base + (size_t)kk * stride + off;
+      if constexpr (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+      } else {
+        v[u][0] = *p;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < k1) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) s[t] += v[u][t];
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(ReduceJobs t) {
   ESC_PRIO();
-  __shared__ float4 part[3][64];
+  __shared__ float part[3][64][4];
   int j = 0;
   while (j + 1 < t.count && (int)blockIdx.x >= t.block_start[j + 1]) ++j;
   const esc_reduce_job& q = t.job[j];
   const int blk = (int)blockIdx.x - t.block_start[j];
-  if (t.vec[j]) {
-    // a workgroup owns 64 consecutive gradient quads; its four waves each add a quarter of the slabs (in split order,
-    // 8 reads in flight), wave 0 then adds the four shares in wave order: a fixed association, bitwise reproducible.
-    // (One thread per quad walking all 60 slabs of an edge-sized gradient left 64 workgroups on the chip: 24 us.)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t nq = q.n / 4;
-    const int64_t nblk = (nq + 63) / 64;                    // blocks that cover the weight gradient
-    if (blk < nblk) {
-      const int64_t i = (int64_t)blk * 64 + lane;
-      const int per = (q.splits + 3) / 4;
-      const int k0 = w * per, k1 = min(q.splits, k0 + per);
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nq) {
-        int k = k0;
-        for (; k + 8 <= k1; k += 8) {
-          float4 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q.slabs + (size_t)(k + u) * q.n + 4 * i);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-        }
-        for (; k < k1; ++k) {
-          const float4 v = *reinterpret_cast<const float4*>(q.slabs + (size_t)k * q.n + 4 * i);
-          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-      }
-      if (w > 0) part[w - 1][lane] = s;
-      __syncthreads();
-      if (w == 0 && i < nq) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) { const float4 o = part[p][lane]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
-        const int64_t e = 4 * i;
-        *reinterpret_cast<float4*>(q.dw + (e / q.cols) * q.ld_dw + (e % q.cols)) = s;
-      }
-    } else if (q.db != nullptr) {
-      const int64_t r = (int64_t)(blk - nblk) * 256 + threadIdx.x;
-      if (r < q.rows) {
-        float s = 0.f;
-        for (int k = 0; k < q.splits; ++k) s += q.db_part[(size_t)k * q.rows + r];
-        q.db[r] = s;
-      }
-    }
-    return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = (q.splits + 3) / 4;
+  const int k0 = min(q.splits, w * per), k1 = min(q.splits, k0 + per);
+  const bool vec = t.vec[j] != 0;
+  const int64_t units = vec ? q.n / 4 : q.n;
+  const int64_t nblk = (units + 63) / 64;                   // blocks that cover the weight gradient; bias rows follow
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool bias = blk >= nblk;
+  const int64_t i = bias ? (int64_t)(blk - nblk) * 64 + lane : (int64_t)blk * 64 + lane;
+  const bool live = bias ? (q.db != nullptr && i < q.rows) : i < units;
+  if (bias) {
+    float o[1];
+    slab_sum<1>(q.db_part, q.rows, k0, k1, i, live, o);
+    s[0] = o[0];
+  } else if (vec) {
+    slab_sum<4>(q.slabs, q.n, k0, k1, 4 * i, live, s);
+  } else {
+    float o[1];
+    slab_sum<1>(q.slabs, q.n, k0, k1, i, live, o);
+    s[0] = o[0];
   }
-  const int64_t i = (int64_t)blk * blockDim.x + threadIdx.x;
-  if (i < q.n) {
-    float s = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < q.splits; ++k) s += q.slabs[(size_t)k * q.n + i];
-    q.dw[(i / q.cols) * q.ld_dw + (i % q.cols)] = s;
-  } else if (q.db != nullptr && i - q.n < q.rows) {
-    const int64_t r = i - q.n;
-    float s = 0.f;
-    for (int k = 0; k < q.splits; ++k) s += q.db_part[(size_t)k * q.rows + r];
-    q.db[r] = s;
+  if (w > 0) { part[w - 1][lane][0] = s[0]; part[w - 1][lane][1] = s[1]; part[w - 1][lane][2] = s[2]; part[w - 1][lane][3] = s[3]; }
+  __syncthreads();
+  if (w != 0 || !live) return;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { s[0] += part[p][lane][0]; s[1] += part[p][lane][1]; s[2] += part[p][lane][2]; s[3] += part[p][lane][3]; }
+  if (bias) {
+    q.db[i] = s[0];
+  } else if (vec) {
+    const int64_t e = 4 * i;
+    *reinterpret_cast<float4*>(q.dw + (e / q.cols) * q.ld_dw + (e % q.cols)) = make_float4(s[0], s[1], s[2], s[3]);
+  } else {
+    q.dw[(i / q.cols) * q.ld_dw + (i % q.cols)] = s[0];
   }
 }
 
@@ -1372,7 +1384,7 @@ int esc_slab_reduce_jobs(const esc_reduce_job* jobs, int count, void* stream) {
     const esc_reduce_job& q = jobs[j];
     const bool vec = q.n % 4 == 0 && q.cols % 4 == 0 && q.ld_dw % 4 == 0 && aligned16(q.slabs) && aligned16(q.dw);
     t.vec[j] = vec ? 1 : 0;
-    blocks += vec ? (int)(cdiv(q.n / 4, 64) + (q.db ? cdiv(q.rows, 256) : 0)) : (int)cdiv(q.n + (q.db ? q.rows : 0), 256);
+    blocks += (int)(cdiv(vec ? q.n / 4 : q.n, 64) + (q.db ? cdiv(q.rows, 64) : 0));
   }
   t.block_start[count] = blocks;
   esc::launch(ESC_K_LINEAR, slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
