@@ -170,11 +170,14 @@ static int g_use_side_stream = 0;     // esc_engine_set_side_stream(); measured 
 // (152 workgroups on 256 CUs) leave idle.  One event per dependency, no host synchronisation.
 struct EdgeStream {
   hipStream_t stream = nullptr;
-  hipEvent_t z_ready = nullptr, joined = nullptr, lin1_fork = nullptr, lin1_rest = nullptr, e_ready[ESC_MAX_LAYERS] = {}, de_ready[ESC_MAX_LAYERS] = {},
+  hipEvent_t z_ready = nullptr, joined = nullptr, lin1_fork = nullptr, lin1_rest = nullptr, tail_dz = nullptr, e_ready[ESC_MAX_LAYERS] = {}, de_ready[ESC_MAX_LAYERS] = {},
              agg_done[ESC_MAX_LAYERS] = {};
   bool ok = false;
 };
-static int g_split_last_lin = getenv("ESC_SPLIT_LAST_LIN") ? atoi(getenv("ESC_SPLIT_LAST_LIN")) : 1;   // see backward(): l == 0
+// 1: the weight gradient of the LAST conv.lin backward (l == 0, in the tail of the step) runs on the node stream.  Measured
+// neutral (1.038 vs 1.031-1.044 ms by the phase marks; so was doing the same for z_embedding's Linear): the node stream's
+// own reductions then become the end of the step.  Off.
+static int g_split_last_lin = getenv("ESC_SPLIT_LAST_LIN") ? atoi(getenv("ESC_SPLIT_LAST_LIN")) : 0;
 static int g_edge_priority_low = 1;
 static int g_use_edge_stream = 1;     // esc_engine_set_side_stream() bit 1
 static int current_device() {
@@ -196,6 +199,7 @@ static EdgeStream& edge_stream() {
     good = good && hipEventCreateWithFlags(&es.joined, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&es.lin1_fork, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&es.lin1_rest, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&es.tail_dz, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l < ESC_MAX_LAYERS; ++l) {
       good = good && hipEventCreateWithFlags(&es.e_ready[l], hipEventDisableTiming) == hipSuccess;
       good = good && hipEventCreateWithFlags(&es.de_ready[l], hipEventDisableTiming) == hipSuccess;
@@ -648,8 +652,11 @@ static int backward(const Ctx& c, Pending* defer) {
   ESC_TRY(bn_backward(ce, y.Yz, H, nullptr, 0, y.dZemb, H, E, y.zb1, m->zbn1, y.dZemb, H, ce.y.bn_scratch));
   Ctx ct = ce;
   ct.on_edge_stream = ce.on_edge_stream && g_cap_tail;    // the tail is the critical path: its GEMM runs at full occupancy
-  if (mat) ESC_TRY(linear_backward(ct, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
-  else     ESC_TRY(linear_backward(ct, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
+  if (mat) {
+    ESC_TRY(linear_backward(ct, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
+  } else {
+    ESC_TRY(linear_backward(ct, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
+  }
   ESC_TRY(bn_backward(ce, y.Zb, H, nullptr, 0, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, ce.y.bn_scratch));
   ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E,
                                  1, m->dz_table, y.bag_scratch, ce.s));

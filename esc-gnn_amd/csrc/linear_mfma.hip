@@ -738,7 +738,8 @@ static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (l
 // rows sit in registers, dot products by wave reduction.  Backward: dX rows and the workgroup's share of dW / db in
 // one pass; the shares are summed by the ordinary slab-reduce job (deterministic, one share per 128 rows).
 // =================================================================================================
-constexpr int NARROW_N = 4, NARROW_K = 256, NARROW_ROWS = 128;   // measured: at N = 10 the wave reductions cost more than the padded MFMA tile
+constexpr int NARROW_N = 4, NARROW_K = 256;                      // measured: at N = 10 the wave reductions cost more than the padded MFMA tile
+constexpr int NARROW_ROWS = 32;                                  // rows per workgroup of linear_narrow_bwd: 2 400 rows = 75 workgroups (128 left 19 on 256 CUs)
 
 template <int NMAX, bool PRO, bool FOLD = false>
 __global__ __launch_bounds__(256) void linear_narrow_fwd(const float* __restrict__ X, int64_t ldx,
@@ -894,18 +895,20 @@ __global__ __launch_bounds__(256) void linear_narrow_dx(const float* __restrict_
   ESC_PRIO();
   const int lane = lane_id();
   const int k = lane * 4;
-  if (k >= K) return;
+  const bool valid = k < K;                                 // (every lane stays: lanes < N carry the dY values of a row)
   float4 w[NMAX];
 #pragma unroll
   for (int n = 0; n < NMAX; ++n)
-    w[n] = n < N ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[n] = (valid && n < N) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int stride = gridDim.x * 4;
   for (int r0 = blockIdx.x * 4 + (threadIdx.x >> 6); r0 < M; r0 += 4 * stride) {
     float4 d[4];
+    float gy[4];                                            // lane n < N holds dY[r, n] of each of the wave's four rows: ONE load per row
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = r0 + u * stride;
-      d[u] = (accumulate && r < M) ? *reinterpret_cast<const float4*>(dX + (size_t)r * lddx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[u] = (valid && accumulate && r < M) ? *reinterpret_cast<const float4*>(dX + (size_t)r * lddx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gy[u] = (r < M && lane < N) ? dY[(size_t)r * lddy + lane] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -914,12 +917,12 @@ __global__ __launch_bounds__(256) void linear_narrow_dx(const float* __restrict_
 #pragma unroll
       for (int n = 0; n < NMAX; ++n) {
         if (n < N) {
-          const float g = dY[(size_t)r * lddy + n];
+          const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gy[u]), n));
           d[u].x = fmaf(g, w[n].x, d[u].x); d[u].y = fmaf(g, w[n].y, d[u].y);
           d[u].z = fmaf(g, w[n].z, d[u].z); d[u].w = fmaf(g, w[n].w, d[u].w);
         }
       }
-      *reinterpret_cast<float4*>(dX + (size_t)r * lddx + k) = d[u];
+      if (valid) *reinterpret_cast<float4*>(dX + (size_t)r * lddx + k) = d[u];
     }
   }
 }
