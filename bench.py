@@ -266,7 +266,8 @@ def main():
         traffic = tj.get("traffic_bytes_per_launch")
         tsrc = ("committed PMC passes of this command (profiles/%s: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
                 "runs, FETCH x2 gfx950 correction, tools/parse_pmc.py) - NOT measured in this run" % os.path.basename(tpaths[-1]))
-    roofline = dict(kernel="esc::agg_fwd_wave<4> (GINE aggregate forward = the scatter-add, C=%d)" % args.hidden,
+    roofline = dict(kernel="esc::agg_fwd_wave<4, true> (GINE aggregate forward = the scatter-add, C=%d; the gathered rows get the previous "
+                           "layer's BatchNorm+ReLU applied as they are read)" % args.hidden,
                     bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None if traffic is None else int(traffic),
                     traffic_source=tsrc,

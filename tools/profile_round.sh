@@ -21,11 +21,11 @@ python3 tools/step_timeline.py "$(find "$OUT/kt" -name '*kernel_trace.csv' | hea
 python3 - "$OUT/${TAG}_bench_kernel_stats.csv" "$OUT/${TAG}_bench_under_rocprof.json.log" > "$OUT/${TAG}_roofline_check.txt" <<'PY' || true
 import csv, json, sys
 rows = {r["Name"]: r for r in csv.DictReader(open(sys.argv[1]))}
-agg = next((r for n, r in rows.items() if "agg_fwd_wave<4>" in n), None)
+agg = next((r for n, r in rows.items() if "agg_fwd_wave<4" in n), None)
 line = json.loads(open(sys.argv[2]).read())
 rf = line["roofline"]
 alg = rf["alg_bytes_per_launch"]
-print("same traced run, kernel esc::agg_fwd_wave<4>:")
+print("same traced run, kernel esc::agg_fwd_wave<4, true> (the wide scatter-add launches of the step):")
 if agg:
     t = float(agg["AverageNs"]) * 1e-3
     print("  rocprofv3 kernel stats : %d calls, average %.2f us -> %.0f GB/s = %.3f of 8 TB/s" % (int(agg["Calls"]), t, alg / t / 1e3, alg / t / 1e3 / 8000))
@@ -43,7 +43,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write
 echo "[profile] WRITE_SIZE pass done"
 F=$(find "$OUT/pmc_fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/pmc_write" -name '*counter_collection.csv' | head -1)
-python3 tools/parse_pmc.py "$F" "$W" "agg_fwd_wave<4>" "$OUT/${TAG}_traffic_agg_fwd.json"
+python3 tools/parse_pmc.py "$F" "$W" "agg_fwd_wave<4" "$OUT/${TAG}_traffic_agg_fwd.json"
 grep -E "agg_fwd_wave|bag_fwd|Kernel_Name" "$F" > "$OUT/${TAG}_pmc_fetch_agg_bag.csv" || true
 grep -E "agg_fwd_wave|bag_fwd|Kernel_Name" "$W" > "$OUT/${TAG}_pmc_write_agg_bag.csv" || true
 
