@@ -139,5 +139,7 @@ class Batch(Data):
 
     @property
     def num_graphs(self):
-        """Number of graphs in the batch (reference batch.py:214-217)."""
-        return int(self.batch[-1].item()) + 1
+        """Number of graphs in the batch (reference batch.py:214-217).  A batch that came from the device collate knows the
+        count on the host (no device read-back, which would stall the caller until the stream has drained)."""
+        n = self.__dict__.get("_num_graphs")
+        return n if n is not None else int(self.batch[-1].item()) + 1

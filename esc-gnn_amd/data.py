@@ -35,6 +35,8 @@ class Data(object):
             object.__setattr__(self, name, value)
         else:
             self._store[name] = value
+            if name == "batch":                              # a host-cached graph count (device collate) belonged to the old vector
+                object.__getattribute__(self, "__dict__").pop("_num_graphs", None)
 
     def __delattr__(self, name):
         if name in self._store:

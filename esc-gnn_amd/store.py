@@ -226,6 +226,7 @@ class DeviceGraphStore(object):
                          n_cols=N_COLS)
         plan._keepalive = (slab, offs_d, ids_d)
         plan.graph_ptr, plan.num_graphs = offs_d[0].to(torch.int32), B      # node range of every graph (readout pooling)
+        object.__setattr__(out, "_num_graphs", B)
         plan._key = plan_key(out, N_COLS)                    # valid as long as nobody swaps or edits the index tensors
         object.__setattr__(out, "_esc_plan", plan)
         has_attr = self.edge_attr_all is not None
