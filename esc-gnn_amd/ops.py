@@ -499,10 +499,13 @@ def embedding(weight, index):
     return _Embedding.apply(weight, index)
 
 
-def embed_plan(index, dims):
+def embed_plan(index, dims, known_range=None):
     """bag plan of a sum-of-embeddings lookup over the concatenated tables: CSR by output row (idx32, row_ptr, ones) and
     CSC by table row (col_ptr, c_row, c_col); depends only on the index tensor — built once (esc_plan_csr) and cached
-    on it (the bond features of a batch are looked up by every layer)."""
+    on it (the bond features of a batch are looked up by every layer).
+    known_range = (per-column minima, per-column maxima) of the DATASET the rows were gathered from (the device store
+    computes them once): when they lie inside `dims` the per-batch range check — a device read-back that drains the
+    stream — is skipped."""
     from .plan import _csr
     cache = getattr(index, "_esc_embed", None)
     if cache is not None and cache[0] == (dims, index._version):
@@ -510,13 +513,16 @@ def embed_plan(index, dims):
     n, k = index.shape
     dev = index.device
     dims_t = torch.tensor(dims, dtype=torch.int64, device=dev)
-    if n and bool(((index < 0) | (index >= dims_t)).any()):        # one check per index tensor, not per lookup
+    trusted = (known_range is not None and len(known_range[0]) == k == len(dims) and
+               all(lo >= 0 and hi < d for lo, hi, d in zip(known_range[0], known_range[1], dims)))
+    if not trusted and n and bool(((index < 0) | (index >= dims_t)).any()):        # one check per index tensor, not per lookup
         raise IndexError("embedding index out of range")
     offs = torch.zeros(k, dtype=torch.int64, device=dev)
     offs[1:] = torch.cumsum(dims_t, 0)[:-1]
     flat = (index + offs).reshape(-1)
     rows = int(sum(dims))
-    col_ptr, order = _csr(flat, rows)                # stable grouping by table row (csrc/plan.hip)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev) if trusted else None    # keys known in range: no read-back
+    col_ptr, order = _csr(flat, rows, bad=flag)      # stable grouping by table row (csrc/plan.hip)
     order = order.long()
     plan = dict(idx32=flat.to(torch.int32), row_ptr=torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev),
                 ones=torch.ones(n * k, dtype=torch.int32, device=dev), col_ptr=col_ptr,

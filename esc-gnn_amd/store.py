@@ -54,6 +54,7 @@ class DeviceGraphStore(object):
         self.x_all = torch.cat([d.x.reshape(d.x.size(0), -1).float() for d in data_list]).contiguous().to(dev)
         ea = [d.edge_attr for d in data_list]
         self.edge_attr_all = None if any(a is None for a in ea) else torch.cat(ea, dim=0).contiguous().to(dev)
+        self._compute_int_ranges()
         self.y_all = torch.cat(ys).float().contiguous().to(dev)
         self.x_dim, self.y_dim = self.x_all.size(1), self.y_all.size(1)
         self.y_is_vector = all(d.y.dim() <= 1 for d in data_list)
@@ -81,6 +82,18 @@ class DeviceGraphStore(object):
         gc_ptr, self.c_perm_all = _stable_group(gc_key, G * N_COLS)
         self.c_rank_all = (torch.arange(Zz, device=dev) - gc_ptr[gc_key[self.c_perm_all]]).to(torch.int32)
         self.col_cnt_all = (gc_ptr[1:] - gc_ptr[:-1]).to(torch.int32).view(G, N_COLS).contiguous()
+
+    def _compute_int_ranges(self):
+        """value range of the integer features, per column: batches gathered from this store are known to stay inside it,
+        so the embedding encoders need no per-batch range check (a device read-back that drains the stream)"""
+        self.int_ranges = {}
+        if self.x_is_int and self.x_all.numel():
+            xi = self.x_all.long()
+            self.int_ranges["x"] = (xi.min(0)[0].tolist(), xi.max(0)[0].tolist())
+        ea = self.edge_attr_all
+        if ea is not None and not ea.is_floating_point() and ea.numel():
+            ea2 = ea.reshape(ea.size(0), -1)
+            self.int_ranges["edge_attr"] = (ea2.min(0)[0].tolist(), ea2.max(0)[0].tolist())
 
     def __len__(self):
         return self.num_graphs
@@ -144,6 +157,7 @@ class DeviceGraphStore(object):
         self.edge_attr_all = None                             # optional tensors are absent from the blob when None
         for k, v in blob.items():
             setattr(self, k, v if (k in cls._HOST or k in cls._META) else v.to(dev))
+        self._compute_int_ranges()
         return self
 
     def nbytes(self):
@@ -227,6 +241,7 @@ class DeviceGraphStore(object):
         plan._keepalive = (slab, offs_d, ids_d)
         plan.graph_ptr, plan.num_graphs = offs_d[0].to(torch.int32), B      # node range of every graph (readout pooling)
         object.__setattr__(out, "_num_graphs", B)
+        object.__setattr__(out, "_esc_int_ranges", getattr(self, "int_ranges", None))
         plan._key = plan_key(out, N_COLS)                    # valid as long as nobody swaps or edits the index tensors
         object.__setattr__(out, "_esc_plan", plan)
         has_attr = self.edge_attr_all is not None
