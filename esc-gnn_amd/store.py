@@ -230,7 +230,7 @@ class DeviceGraphStore(object):
         if self.edge_attr_all is not None:                   # per-edge attributes: gather by a device-built index
             cnt = (offs_d[1, 1:] - offs_d[1, :-1])
             src0 = self.edge_ptr[ids_d]
-            gather = torch.arange(E, device=dev) + torch.repeat_interleave(src0 - offs_d[1, :-1], cnt)
+            gather = torch.arange(E, device=dev) + torch.repeat_interleave(src0 - offs_d[1, :-1], cnt, output_size=E)   # (output_size: no read-back)
             out.edge_attr = self.edge_attr_all[gather]
         out.y = y.view(-1) if (self.y_is_vector and self.y_dim == 1) else y
         out.pos_enc, out.pos_index, out.pos_batch, out.batch = pos_enc, pos_index, pos_batch, batch
