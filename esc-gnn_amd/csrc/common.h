@@ -93,6 +93,8 @@ int edge_lds_floor();
 void set_edge_lds_floor(int bytes);
 int norm_rowblock_cap();              // workgroups per column block of the BatchNorm reduction kernels (esc_tune_set(9, v))
 void set_norm_rowblock_cap(int v);
+bool bn_bwd_one_launch();              // node-sized BatchNorm backward as ONE launch with a grid barrier (esc_tune_set(13, v))
+void set_bn_bwd_one_launch(int on);
 bool bn_bwd_fold();                    // node-sized BatchNorm backward: the apply kernel adds the partial slots itself (esc_tune_set(12, v))
 void set_bn_bwd_fold(int on);
 bool last_block_finalize();

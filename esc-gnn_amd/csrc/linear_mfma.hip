@@ -1037,6 +1037,7 @@ int esc_tune_set(int knob, int value) {
   if (knob == 8) { set_last_block_finalize(value); return ESC_OK; }
   if (knob == 9) { set_norm_rowblock_cap(value); return ESC_OK; }
   if (knob == 12) { set_bn_bwd_fold(value); return ESC_OK; }
+  if (knob == 13) { set_bn_bwd_one_launch(value); return ESC_OK; }
   if (knob == 10) { set_edge_lds_floor(value); return ESC_OK; }
   if (knob == 11) { g_use_dma = value; return ESC_OK; }
   ESC_REQUIRE(knob >= 0 && knob < KNOB_COUNT, "esc_tune_set: unknown knob %d", knob);

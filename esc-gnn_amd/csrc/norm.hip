@@ -580,6 +580,139 @@ __global__ __launch_bounds__(256) void bn_sync_coef_kernel(float2* __restrict__ 
 
 // >= 4 rows per wave slot (scalar kernels keep the old 64-block cap: their finalize cost grows with the slot count)
 // forward statistics: 64 (their finalize merges 4 slots per block with Chan's formula, its cost grows with the count);
+// ---- node-sized BatchNorm backward in ONE launch ---------------------------------------------------------------------------
+// partial sums -> grid barrier -> every workgroup adds the slots of its 256 columns -> dX from the rows it still holds in
+// registers.  Replaces partial + finalize + apply (three dependent launches at the ~4.5 us floor each, 13 times per training
+// step of the counting model).  The barrier is an agent-scope counter pair from the ticket pool: workgroups arrive, spin
+// (bounded: a workgroup that gives up raises *err and the results are invalid, but nothing hangs) and the last one to LEAVE
+// re-zeroes the pair.  All gridDim.y <= 256 workgroups of a column block are small (256 threads, 3 KB LDS), so they are
+// co-resident unless other kernels occupy every CU — those finish without waiting for this one, so the spin always ends.
+// Rows per wave are fixed (4, in registers): the host picks gridDim.y = ceil(M / 16).
+template <int ACT, bool HAS_Y>
+__global__ __launch_bounds__(256) void bn_bwd_node_kernel(const float* __restrict__ X, int64_t ldx,
+                                                          const float* __restrict__ Y, int64_t ldy,
+                                                          const float* __restrict__ dY, int64_t ldg, int M, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float2* slots, unsigned* bar, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ dX, int64_t ldd,
+                                                          int* err) {
+  ESC_PRIO();
+  constexpr int relu = ACT;
+  constexpr int RPW = 4;
+  __shared__ float4 sh[3][2][64];
+  __shared__ float2 coef_s[256];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const bool active = c < C;
+  const int P = gridDim.y * 4;
+  const int slot0 = blockIdx.y * 4 + wave;
+  float4 gq[RPW], xq[RPW];
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, ga = make_float4(1.f, 1.f, 1.f, 1.f), be = mu;
+  float4 s1 = mu, s2 = mu;
+  if (active) {
+    mu = *reinterpret_cast<const float4*>(mean + c); is = *reinterpret_cast<const float4*>(invstd + c);
+    if (gamma) ga = *reinterpret_cast<const float4*>(gamma + c);
+    if (beta) be = *reinterpret_cast<const float4*>(beta + c);
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int r = slot0 + j * P;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), xh = g;
+      if (r < M) {
+        g = *reinterpret_cast<const float4*>(dY + (size_t)r * ldg + c);
+        const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
+        xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
+        if constexpr (ACT != 0) {
+          if constexpr (HAS_Y) {
+            const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+            g.x *= act_grad_from_out(y.x, relu); g.y *= act_grad_from_out(y.y, relu);
+            g.z *= act_grad_from_out(y.z, relu); g.w *= act_grad_from_out(y.w, relu);
+          } else {
+            g.x *= act_grad_from_pre(pre_act_fwd(x.x, mu.x, is.x, ga.x, be.x), relu); g.y *= act_grad_from_pre(pre_act_fwd(x.y, mu.y, is.y, ga.y, be.y), relu);
+            g.z *= act_grad_from_pre(pre_act_fwd(x.z, mu.z, is.z, ga.z, be.z), relu); g.w *= act_grad_from_pre(pre_act_fwd(x.w, mu.w, is.w, ga.w, be.w), relu);
+          }
+        }
+        s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+        s2.x = fmaf(g.x, xh.x, s2.x); s2.y = fmaf(g.y, xh.y, s2.y); s2.z = fmaf(g.z, xh.z, s2.z); s2.w = fmaf(g.w, xh.w, s2.w);
+      }
+      gq[j] = g; xq[j] = xh;
+    }
+  }
+  if (wave > 0) { sh[wave - 1][0][lane] = s1; sh[wave - 1][1][lane] = s2; }
+  __syncthreads();
+  if (wave == 0 && active) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float4 a = sh[w][0][lane], b = sh[w][1][lane];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    float2* dst = slots + (size_t)blockIdx.y * C + c;
+    store_agent(dst, make_float2(s1.x, s2.x));
+    store_agent(dst + 1, make_float2(s1.y, s2.y));
+    store_agent(dst + 2, make_float2(s1.z, s2.z));
+    store_agent(dst + 3, make_float2(s1.w, s2.w));
+  }
+  // ---- grid barrier over the gridDim.y workgroups of this column block
+  unsigned* arrive = bar + 2 * blockIdx.x;
+  unsigned* leave = arrive + 1;
+  __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): the write-through slot stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.y) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) { if (err) *err = 1; break; }      // ~seconds: never in a healthy run
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // the slots are read from memory, not from stale lines
+  // ---- every workgroup adds the slots of its 256 columns (slot order, fp64 like the finalize kernel)
+  {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    double t1 = 0.0, t2 = 0.0;
+    if (col < C) {
+      const int nb = gridDim.y;
+      int p = 0;
+      for (; p + 8 <= nb; p += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slots[(size_t)(p + u) * C + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { t1 += (double)v[u].x; t2 += (double)v[u].y; }
+      }
+      for (; p < nb; ++p) { const float2 v = slots[(size_t)p * C + col]; t1 += (double)v.x; t2 += (double)v.y; }
+      if (blockIdx.y == 0) {
+        if (dgamma) dgamma[col] = (float)t2;
+        if (dbeta) dbeta[col] = (float)t1;
+      }
+    }
+    coef_s[threadIdx.x] = make_float2((float)(t1 / M), (float)(t2 / M));
+  }
+  __syncthreads();
+  if (active) {
+    const float2 k0 = coef_s[lane * 4], k1 = coef_s[lane * 4 + 1], k2 = coef_s[lane * 4 + 2], k3 = coef_s[lane * 4 + 3];
+    const float4 a = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int r = slot0 + j * P;
+      if (r < M)
+        *reinterpret_cast<float4*>(dX + (size_t)r * ldd + c) =
+            make_float4(a.x * (gq[j].x - k0.x - xq[j].x * k0.y), a.y * (gq[j].y - k1.x - xq[j].y * k1.y),
+                        a.z * (gq[j].z - k2.x - xq[j].z * k2.y), a.w * (gq[j].w - k3.x - xq[j].w * k3.y));
+    }
+  }
+  // ---- the last workgroup to leave re-zeroes the counter pair for the next launch that draws it from the pool
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.y - 1) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // backward sums: norm_rowblock_cap() = 256 (one slot per block, plain sums) — swept on MI355X: 35 -> 28 us edge-sized
 static inline int rowblocks(int64_t M, bool wide, bool backward = false) {
   const int64_t cap = (wide && backward) ? norm_rowblock_cap() : 64;
@@ -810,6 +943,19 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   const bool all16 = aligned16(X) && aligned16(dY) && aligned16(dX) && (!Y || aligned16(Y)) && aligned16(mean) && aligned16(invstd) &&
                      (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && aligned16(partial) &&
                      (!dgamma || aligned16(dgamma)) && (!dbeta || aligned16(dbeta));
+  if (bn_bwd_one_launch() && M >= 64 && M <= 4096 && C % 4 == 0 && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0 && (!Y || ld_y % 4 == 0) && all16) {
+    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)cdiv(M, 16));
+    unsigned* bar = tickets(2 * (int)grid.x);
+    ESC_REQUIRE(bar != nullptr, "esc_bn_bwd: no barrier counters");
+    int* noerr = nullptr;
+#define ESC_BWD_NODE(A, H) esc::launch(ESC_K_NORM, bn_bwd_node_kernel<A, H>, grid, dim3(256), 0, s, X, ld_x, Y, ld_y, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial, bar, dgamma, dbeta, dX, ld_dx, noerr)
+    if (relu == 0)      ESC_BWD_NODE(0, false);
+    else if (relu == 1) { if (Y) ESC_BWD_NODE(1, true); else ESC_BWD_NODE(1, false); }
+    else                { if (Y) ESC_BWD_NODE(2, true); else ESC_BWD_NODE(2, false); }
+#undef ESC_BWD_NODE
+    ESC_CHECK_LAUNCH("esc_bn_bwd.node");
+    return ESC_OK;
+  }
   if (bn_bwd_fold() && M >= 64 && M <= 4096 && C % 4 == 0 && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0 && (!Y || ld_y % 4 == 0) && all16 &&
       !last_block_finalize()) {
     const int rb = (int)(cdiv(M, 32) < 32 ? cdiv(M, 32) : 32);

@@ -1,5 +1,6 @@
 // runtime.hip — error reporting + HIP-event kernel-family profiler of libescgnn_hip.so
 #include "common.h"
+#include <cstdlib>
 
 #include <mutex>
 #include <vector>
@@ -56,6 +57,9 @@ static int g_edge_lds_floor = 52 * 1024;      // 3 edge-GEMM workgroups per CU: 
 int edge_lds_floor() { return g_edge_lds_floor; }
 void set_edge_lds_floor(int bytes) { g_edge_lds_floor = bytes < 0 ? 0 : bytes; }
 
+static int g_bn_bwd_one = getenv("ESC_BN_BWD_ONE") ? atoi(getenv("ESC_BN_BWD_ONE")) : 0;
+bool bn_bwd_one_launch() { return g_bn_bwd_one != 0; }
+void set_bn_bwd_one_launch(int on) { g_bn_bwd_one = on != 0; }
 static int g_bn_bwd_fold = 0;      // measured on MI355X r02: 1.298 ms with it vs 1.215 ms without (the 32-block partial pass is slower than what the finalize launch costs)
 bool bn_bwd_fold() { return g_bn_bwd_fold != 0; }
 void set_bn_bwd_fold(int on) { g_bn_bwd_fold = on != 0; }
