@@ -656,9 +656,13 @@ def _ogb_batch(model, data, need_y, seed):
         data.to(dev)
     plan = plan_of(data, Z_TABLE_ROWS)
     gptr, G = graph_ptr_of(data, plan)
-    rng = data.__dict__.get("_esc_int_ranges") or {}          # from the device store: no per-batch range read-back
-    pa = embed_plan(data.x, ATOM_FEATURE_DIMS, rng.get("x"))
-    pb = embed_plan(data.edge_attr, BOND_FEATURE_DIMS, rng.get("edge_attr"))
+    rng, sig = data.__dict__.get("_esc_int_ranges") or ({}, {})      # from the device store: no per-batch range read-back
+
+    def known(key):                                          # ... as long as the tensor is the collate's, unedited
+        t = data[key]
+        return rng.get(key) if sig.get(key) == (t.data_ptr(), t._version) else None
+    pa = embed_plan(data.x, ATOM_FEATURE_DIMS, known("x"))
+    pb = embed_plan(data.edge_attr, BOND_FEATURE_DIMS, known("edge_attr"))
     b = _OgbBatch()
     b.N, b.E, b.Z, b.G = plan.num_nodes, plan.num_edges, plan.nnz, G
     if data.x.size(0) != b.N or data.edge_attr.size(0) != b.E:

@@ -241,7 +241,9 @@ class DeviceGraphStore(object):
         plan._keepalive = (slab, offs_d, ids_d)
         plan.graph_ptr, plan.num_graphs = offs_d[0].to(torch.int32), B      # node range of every graph (readout pooling)
         object.__setattr__(out, "_num_graphs", B)
-        object.__setattr__(out, "_esc_int_ranges", getattr(self, "int_ranges", None))
+        # the dataset-wide value range of the integer features, valid for exactly these tensors in their current version
+        sig = {k: (out[k].data_ptr(), out[k]._version) for k in ("x", "edge_attr") if out[k] is not None}
+        object.__setattr__(out, "_esc_int_ranges", (getattr(self, "int_ranges", None) or {}, sig))
         plan._key = plan_key(out, N_COLS)                    # valid as long as nobody swaps or edits the index tensors
         object.__setattr__(out, "_esc_plan", plan)
         has_attr = self.edge_attr_all is not None

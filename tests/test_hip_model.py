@@ -588,3 +588,31 @@ def test_engine_node_writes_into_a_clean_flatadam_bucket():
         for n, p in m2.named_parameters():
             _close(p.grad, want[n].cpu(), "accumulate-path grad " + n, tol=2e-5)
         opt.engine_direct = True
+
+
+def test_ogb_engine_trusts_store_features_only_while_untouched():
+    """batches from the device store skip the per-batch range check of the atom / bond features (the store knows the range
+    of its dataset); a feature tensor edited after the collate is checked again and an out-of-range id raises instead of
+    reading outside the embedding tables"""
+    require_gpu()
+    import esc_gnn_amd as E
+    from esc_gnn_amd import ogb_mol_gnn as og
+    from esc_gnn_amd.engine import OgbStepEngine
+    graphs, _, _ = load_collate("molhiv4")
+    store = E.DeviceGraphStore([E.Data(**{k: torch.tensor(v) for k, v in g.items()}) for g in graphs], "cuda:0")
+    assert set(store.int_ranges) == {"x", "edge_attr"}
+    torch.manual_seed(0)
+    m = og.GNN("ogbg-molhiv", 1, num_layer=2, emb_dim=32, gnn_type="gin_eff", virtual_node=True, residual=True,
+               drop_ratio=0.0).to("cuda:0").train()
+    eng = OgbStepEngine(m)
+    b = store.collate([0, 1, 2, 3])
+    assert torch.isfinite(eng.train_step(b))
+    b2 = store.collate([0, 1, 2, 3])
+    b2.x[0, 0] = 500                                  # beyond the 119 atom types: the in-place edit voids the store's guarantee
+    with pytest.raises(IndexError):
+        eng.train_step(b2)
+    b3 = store.collate([0, 1, 2, 3])
+    b3.edge_attr = b3.edge_attr.clone()               # a replaced tensor is not the collate's either
+    b3.edge_attr[0, 0] = 77
+    with pytest.raises(IndexError):
+        eng.train_step(b3)
