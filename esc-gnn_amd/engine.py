@@ -363,6 +363,20 @@ class _EngineNode(torch.autograd.Function):
         return (None, None, None) + grads
 
 
+@torch.no_grad()
+def engine_predict(model, data):
+    """eval-mode `model(batch)` of the counting model as one call (esc_engine_predict: running statistics, no gradient
+    state) — the validation / test passes of a training run are most of its batches"""
+    cache = _node_cache(model)
+    b, keep = StepEngine._batch(model, data, False)
+    desc = cache.descriptor(0)
+    need = nv.lib().esc_engine_workspace_floats(ctypes.byref(desc), b.N, b.E, b.Z)
+    ws = torch.empty(int(need), dtype=torch.float32, device=model.lin1.weight.device)
+    pred = torch.empty(b.N, dtype=torch.float32, device=model.lin1.weight.device)
+    nv.call("esc_engine_predict", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+    return pred.view(-1, 1)
+
+
 def engine_forward(model, data):
     groups = _sync_groups(model)
     if groups and _collective.get("group", False) is not groups[0]:      # SyncBN: the engine needs its all-reduce
@@ -535,6 +549,28 @@ class _ZincEngineNode(torch.autograd.Function):
                       for p, o in zip(cache.params, cache.offsets))
         ctx.ws = ctx.keep = None
         return (None, None, None) + grads
+
+
+def _mol_cache(model, kind):
+    c = model.__dict__.get("_esc_node_cache")
+    if c is None or not c.valid():
+        c = kind(model)
+        model.__dict__["_esc_node_cache"] = c
+    return c
+
+
+@torch.no_grad()
+def zinc_engine_predict(model, data):
+    """eval-mode forward of the ZINC model as one call (esc_zinc_predict)"""
+    cache = _mol_cache(model, _ZincNodeCache)
+    b, keep = _zinc_batch(model, data, False)
+    desc = cache.descriptor(0)
+    need = nv.lib().esc_zinc_workspace_floats(ctypes.byref(desc), b.N, b.E, b.Z, b.G)
+    dev = model.lin1.weight.device
+    ws = torch.empty(int(need), dtype=torch.float32, device=dev)
+    pred = torch.empty(b.G, dtype=torch.float32, device=dev)
+    nv.call("esc_zinc_predict", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+    return pred.view(-1, 1)
 
 
 def zinc_engine_forward(model, data):
@@ -786,6 +822,20 @@ class _OgbEngineNode(torch.autograd.Function):
                       for p, o in zip(cache.params, cache.offsets))
         ctx.ws = ctx.keep = None
         return (None, None, None) + grads
+
+
+@torch.no_grad()
+def ogb_engine_predict(model, data):
+    """eval-mode forward of the OGB model as one call (esc_ogb_predict: no dropout, running statistics)"""
+    cache = _mol_cache(model, _OgbNodeCache)
+    b, keep = _ogb_batch(model, data, False, 0)
+    desc = cache.descriptor(0)
+    need = nv.lib().esc_ogb_workspace_floats(ctypes.byref(desc), b.N, b.E, b.Z, b.G, b.atoms.n_entries, b.bonds.n_entries)
+    dev = model.graph_pred_linear.weight.device
+    ws = torch.empty(int(need), dtype=torch.float32, device=dev)
+    pred = torch.empty((b.G, model.num_tasks), dtype=torch.float32, device=dev)
+    nv.call("esc_ogb_predict", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
+    return pred
 
 
 def ogb_engine_forward(model, data):

@@ -175,5 +175,11 @@ class GNN(torch.nn.Module):
                 data.to(self.graph_pred_linear.weight.device)
             if ogb_engine_ready(self, data):
                 return ogb_engine_forward(self, data)      # one autograd node (csrc/engine.hip esc_ogb_*)
+        if not self.training and not torch.is_grad_enabled() and self.step_engine and perturb is None:
+            from .engine import ogb_engine_predict, ogb_engine_ready
+            if data.edge_index.device != self.graph_pred_linear.weight.device:
+                data.to(self.graph_pred_linear.weight.device)
+            if ogb_engine_ready(self, data):
+                return ogb_engine_predict(self, data)      # eval-mode forward as one call (esc_ogb_predict)
         x = self.gnn_node(data, perturb=perturb)
         return self.graph_pred_linear(self.pool(x, data.batch))

@@ -69,6 +69,12 @@ class NestedGIN_eff(torch.nn.Module):
             from .engine import engine_forward, engine_supports
             if engine_supports(self) and x.size(1) == self.x_embedding[0].in_features:
                 return engine_forward(self, data)       # the whole step as one autograd node (engine.hip)
+        if (not self.training and not torch.is_grad_enabled() and not return_embeddings and self.engine_forward
+                and "edge_pos" not in data and x.is_floating_point() and x.dim() == 2 and x.size(0) >= 2
+                and edge_index.size(1) >= 2 and "pos_batch" in data):
+            from .engine import engine_predict, engine_supports
+            if engine_supports(self) and x.size(1) == self.x_embedding[0].in_features:
+                return engine_predict(self, data)       # eval-mode forward as one call (esc_engine_predict)
         plan = plan_of(data, Z_TABLE_ROWS)
         if "edge_pos" in data:                       # dense layout of the slow variant (reference :142-145)
             z = ops.linear(data.edge_pos.float(), self.z_initial.weight.t().contiguous())

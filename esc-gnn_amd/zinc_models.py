@@ -60,6 +60,10 @@ class NestedGIN_eff(torch.nn.Module):
             from .engine import zinc_engine_forward, zinc_engine_ready
             if zinc_engine_ready(self, data):
                 return zinc_engine_forward(self, data)     # the whole step as one autograd node (csrc/engine.hip esc_zinc_*)
+        if not self.training and not torch.is_grad_enabled() and self.step_engine:
+            from .engine import zinc_engine_predict, zinc_engine_ready
+            if zinc_engine_ready(self, data):
+                return zinc_engine_predict(self, data)     # eval-mode forward as one call (esc_zinc_predict)
         x, edge_index, batch = self.node_type_embedding(data.x.view(-1)), data.edge_index, data.batch
         plan = plan_of(data, Z_TABLE_ROWS)
         if "edge_pos" in data:

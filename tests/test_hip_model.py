@@ -616,3 +616,28 @@ def test_ogb_engine_trusts_store_features_only_while_untouched():
     b3.edge_attr[0, 0] = 77
     with pytest.raises(IndexError):
         eng.train_step(b3)
+
+
+def test_eval_forward_goes_through_the_engine_and_matches_the_per_op_path():
+    """model.eval() + torch.no_grad(): `model(batch)` of the counting model is one esc_engine_predict call; same predictions
+    as the per-op path (engine_forward = False) and as StepEngine.predict; with gradients enabled eval stays per-op"""
+    require_gpu()
+    import esc_gnn_amd as E
+    torch.manual_seed(2)
+    _, b, _ = load_collate("count3")
+    bt = {k: torch.tensor(v) for k, v in b.items()}
+    m = E.NestedGIN_eff(None, 3, 64, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to("cuda:0")
+    m.train()
+    for _ in range(2):                                   # move the running statistics off their initial values
+        m(E.Data(**{k: v.clone() for k, v in bt.items()}))
+    m.eval()
+    with torch.no_grad():
+        fast = m(E.Data(**{k: v.clone() for k, v in bt.items()}))
+        m.engine_forward = False
+        slow = m(E.Data(**{k: v.clone() for k, v in bt.items()}))
+        m.engine_forward = True
+    assert fast.grad_fn is None and fast.shape == slow.shape
+    _close(fast, slow.cpu(), "eval predictions engine vs per-op")
+    _close(E.StepEngine(m).predict(E.Data(**{k: v.clone() for k, v in bt.items()})), slow.cpu(), "StepEngine.predict")
+    out = m(E.Data(**{k: v.clone() for k, v in bt.items()}))          # gradients enabled: differentiable per-op eval path
+    assert out.grad_fn is not None
