@@ -21,6 +21,7 @@
 // dW).  LDS image [k][cols+4]; a lane reads single floats (ds_read_b32, consecutive lanes ->
 // consecutive banks).
 #include "common.h"
+#include <cstdlib>
 #include "gemm_dma.h"
 #include "linear_small.h"
 #include <type_traits>
@@ -948,6 +949,17 @@ static inline bool dma_ok(const void* p, int64_t rows, int64_t ld) {
 // a 128-wide tile dimension over `dim` columns: acceptable when the padding to a multiple of 128 wastes <= 10 % of the MFMA
 // work (256, 600 -> yes; 300 -> 384 is 28 % waste -> 64-wide tiles: 320)
 static inline bool tile128_ok(int64_t dim) { return cdiv(dim, 128) * 128 * 10 <= dim * 11; }
+// forward GEMM on 128-row tiles (4 compute + 4 loader waves, one workgroup per CU): edge-sized inputs.  Mid-sized launches that
+// would still fill the chip with them (ogbg-mol node rows: 6 500 x 600 = 51 x 5 tiles) are faster ALONE on the big tile (32.8 ->
+// 27.7 us) but slower inside the two-stream step (4.87 vs 4.77 ms: a one-workgroup-per-CU tile on the node stream shuts the
+// edge stream's GEMMs out) — ESC_BIG_MIN_WGS=<workgroups> enables the rule for experiments.  The BatchNorm partials of the
+// epilogue are per row tile, so esc_linear_stats_block_rows answers with the same predicate.
+static inline bool dma_big(int64_t M, int64_t N) {
+  if (N < 128) return false;
+  if (M >= 8192) return true;
+  static const int64_t min_wgs = getenv("ESC_BIG_MIN_WGS") ? atoll(getenv("ESC_BIG_MIN_WGS")) : (1LL << 62);
+  return cdiv(M, 128) * cdiv(N, tile128_ok(N) ? 128 : 64) >= min_wgs;
+}
 static inline hipError_t dma_check(hipError_t e, const char* what) {
   if (e != hipSuccess) set_error("%s: %s", what, hipGetErrorString(e));
   return e;
@@ -976,7 +988,7 @@ static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, 
   hipError_t e;
   if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
     e = dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
-  } else if (M >= 8192 && N >= 128) {     // edge-sized: 128x128 tile, 4 compute + 4 loader waves, one workgroup per CU
+  } else if (dma_big(M, N)) {             // edge-sized (or enough 128-row tiles to fill the chip): 128x128 tile, 4 compute + 4 loader waves
     if (in_scale)               e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s);
     else if (tile128_ok(N))     e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
     else                        e = dma::launch_gemm<128, 64, 32, 2, 2, 3, 2, false, false, 0, true, false>(g, 0, s);   // N = 300: 5 x 64 instead of 3 x 128
@@ -1082,7 +1094,7 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
     int rc = ESC_OK;
     if (dma_fwd(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, s, &rc)) {
       if (rc != ESC_OK || bn == nullptr) return rc;
-      return esc_bn_stats_from_partials_rows(col_stats, M, N, (M >= 8192 && N >= 128) ? 128 : 64, bn->eps, bn->momentum, bn->mean,
+      return esc_bn_stats_from_partials_rows(col_stats, M, N, dma_big(M, N) ? 128 : 64, bn->eps, bn->momentum, bn->mean,
                                              bn->invstd, bn->running_mean, bn->running_var, bn->gamma, bn->beta, bn->scale,
                                              bn->shift, stream);
     }
@@ -1127,7 +1139,7 @@ int esc_linear_fold_available(void) { return (g_use_dma & 1) != 0; }
 int64_t esc_linear_stats_block_rows(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N,
                                     int64_t K) {
   if ((g_use_dma & 4) && K <= small::SMALL_MAX && N > 32) return small::ROWS_FWD;
-  if ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w)) return (M >= 8192 && N >= 128) ? 128 : 64;
+  if ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w)) return dma_big(M, N) ? 128 : 64;
   return 32;
 }
 
@@ -1155,7 +1167,7 @@ int esc_linear_fwd_fold(const float* X, int64_t ld_x, const float* W, int64_t ld
   g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
   g.col_stats = reinterpret_cast<float2*>(col_stats); g.fold = f;
   g.M = (int)M; g.N = (int)N; g.R = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
-  const hipError_t e = (M >= 8192 && N >= 128) ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 3, true, false>(g, 0, s)
+  const hipError_t e = dma_big(M, N) ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 3, true, false>(g, 0, s)
                                                : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 3, true, false>(g, 0, s);
   return dma_check(e, "esc_linear_fwd_fold") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
 }
