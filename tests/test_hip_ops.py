@@ -542,3 +542,47 @@ def test_broadcast_add_table_pack_and_accumulating_bag(E):
     for j in range(len(dims)):
         want = want + cat[index[:, j] + offs[j]]
     assert torch.equal(acc, want)
+
+
+def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(E):
+    """esc_gine_aggregate_fwd_affine / _bwd_affine (the layer input given as pre-BatchNorm rows + (scale, shift)) against
+    esc_affine_act followed by the plain aggregate kernels: forward BIT-identical (same fmaf + max, same summation order),
+    backward d_e / dx / deps identical"""
+    from esc_gnn_amd import _native as nv
+    dev = torch.device("cuda:0")
+    b = _batch()
+    plan = _plan(E, b, dev)
+    N, Ee, C = plan.num_nodes, plan.num_edges, 256
+    g0 = torch.Generator().manual_seed(9)
+    ld = C + 8
+    x = torch.randn(N, ld, generator=g0).to(dev)
+    e = torch.randn(Ee, C, generator=g0).to(dev)
+    sc, sh = (torch.rand(C, generator=g0) + 0.5).to(dev), torch.randn(C, generator=g0).to(dev)
+    eps = torch.tensor([0.3], device=dev)
+    s = nv.stream()
+    xa = torch.empty(N, C, device=dev)
+    nv.call("esc_affine_act", nv.ptr(x), ld, N, C, nv.ptr(sc), nv.ptr(sh), 1, nv.ptr(xa), C, s)
+    want, got = torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
+    nv.call("esc_gine_aggregate_fwd", nv.ptr(xa), C, nv.ptr(e), C, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge), nv.ptr(plan.in_src),
+            nv.ptr(eps), N, C, nv.ptr(want), C, s)
+    nv.call("esc_gine_aggregate_fwd_affine", nv.ptr(x), ld, nv.ptr(sc), nv.ptr(sh), nv.ptr(e), C, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge),
+            nv.ptr(plan.in_src), nv.ptr(eps), N, C, nv.ptr(got), C, s)
+    assert torch.equal(got, want)
+    g = torch.randn(N, C, generator=g0).to(dev)
+    outs = []
+    for affine in (False, True):
+        de = torch.empty(Ee, C, device=dev)
+        dx = torch.full((N, C), 0.25, device=dev)            # accumulate_dx = 1: added onto what is there
+        dp = torch.empty(N, device=dev)
+        if affine:
+            nv.call("esc_gine_aggregate_bwd_affine", nv.ptr(x), ld, nv.ptr(sc), nv.ptr(sh), nv.ptr(e), C, nv.ptr(g), C, nv.ptr(plan.out_ptr),
+                    nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, C, nv.ptr(de), C, nv.ptr(dx), C, 1, nv.ptr(dp), s)
+        else:
+            nv.call("esc_gine_aggregate_bwd", nv.ptr(xa), C, nv.ptr(e), C, nv.ptr(g), C, nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge),
+                    nv.ptr(plan.out_dst), nv.ptr(eps), N, C, nv.ptr(de), C, nv.ptr(dx), C, 1, nv.ptr(dp), s)
+        outs.append((de, dx, dp))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
+    with pytest.raises(RuntimeError):                        # narrow rows have no affine variant
+        nv.call("esc_gine_aggregate_fwd_affine", nv.ptr(x), ld, nv.ptr(sc), nv.ptr(sh), nv.ptr(e), C, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge),
+                nv.ptr(plan.in_src), nv.ptr(eps), N, 32, nv.ptr(got), C, s)
