@@ -1,5 +1,6 @@
 import sys, time, torch
-sys.path[:0] = [__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))]
+import os
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))]      # the repo root
 import esc_gnn_amd as E
 from esc_gnn_amd import _native as nv
 from esc_gnn_amd.datasets import synthetic_count_graphs, synthetic_ogbmol_graphs
