@@ -185,7 +185,11 @@ int esc_linear_fwd_fold(const float* X, int64_t ld_x, const float* W, int64_t ld
  * workgroup of the producing launch instead of a finalize launch (measured 1 % slower on the cfg1 step).
  * knob 9 (default 256, 1..512): workgroups per 256-column block of the BatchNorm-backward reduction kernel.
  * knob 10 (default 53248): dynamic-LDS floor in bytes of the GEMMs the step engine launches on its edge stream (caps them
- * at 3 workgroups per CU so that the node stream's kernels find a free wave slot; 0 = no cap). */
+ * at 3 workgroups per CU so that the node stream's kernels find a free wave slot; 0 = no cap).
+ * knob 11 (default 15): bit mask of the LDS-DMA GEMM family (gemm_dma.h) — bit 0 forward, 1 gradients, 2 the tiny-dimension
+ * kernels (linear_small.h), 3 the 64x32 narrow-output tile; 0 = every GEMM on the r01 register-staged tiles (bisecting).
+ * knob 12 (default 0): node-sized BatchNorm backward with the finalize folded into the apply kernel (measured 7 % slower).
+ * knob 13 (default 0): node-sized BatchNorm backward as ONE launch with a grid barrier (measured 9 % slower). */
 int esc_tune_set(int knob, int value);
 int esc_debug_gemm_occupancy(int tile_id);   /* resident workgroups/CU the runtime predicts (diagnostics) */
 /* dX[M,K] = dY[M,N] * W[N,K]  (accumulate!=0: dX += ...) */
