@@ -23,6 +23,15 @@ def _is_number(v):
     return isinstance(v, (int, float)) and not isinstance(v, bool)
 
 
+def _repeat(values, counts, device):
+    """values[i] repeated counts[i] times.  On the host through numpy: torch.repeat_interleave on CPU tensors takes tens of
+    milliseconds per call under a multi-threaded OpenMP runtime (60 ms for 5*10^5 outputs on 8 threads, 0.7 ms in numpy),
+    three calls per batch."""
+    import numpy as np
+    out = torch.from_numpy(np.repeat(values.numpy(), np.asarray(counts, dtype=np.int64)))
+    return out if device is None or torch.device(device).type == "cpu" else out.to(device)
+
+
 class Batch(Data):
     def __init__(self, batch=None, **fields):
         super().__init__(**fields)
@@ -73,19 +82,22 @@ class Batch(Data):
                     running += inc
                 merged = torch.cat([t if t.dim() > 0 else t.view(1) for t in items], dim=dim)
                 if any(offs) and merged.dtype != torch.bool:
-                    off_t = torch.tensor(offs, dtype=merged.dtype, device=merged.device)
-                    off_t = torch.repeat_interleave(off_t, torch.tensor(sizes, device=merged.device))
                     shape = [1] * merged.dim()
                     shape[dim] = -1
-                    merged = merged + off_t.view(shape)
+                    if merged.device.type == "cpu":      # in place through numpy (torch.cat made a fresh tensor): see _repeat
+                        import numpy as np
+                        m = merged.numpy()
+                        m += np.repeat(np.asarray(offs, dtype=m.dtype), np.asarray(sizes, dtype=np.int64)).reshape(shape)
+                    else:
+                        off_t = _repeat(torch.tensor(offs, dtype=merged.dtype), sizes, merged.device)
+                        merged = merged + off_t.view(shape)
                 out[key] = merged
                 bounds = [0]
                 for s in sizes:
                     bounds.append(bounds[-1] + s)
                 slices[key], shifts[key] = bounds, offs
                 if key in follow_batch:
-                    ids = torch.repeat_interleave(torch.arange(len(items)), torch.tensor(sizes))
-                    out["%s_batch" % key] = ids.to(merged.device)
+                    out["%s_batch" % key] = _repeat(torch.arange(len(items)), sizes, merged.device)
             else:
                 out[key] = torch.tensor(items) if _is_number(probe) else list(items)
                 slices[key] = list(range(len(items) + 1))
@@ -100,8 +112,7 @@ class Batch(Data):
                         break
                 if dev is not None:
                     break
-            out.batch = torch.repeat_interleave(torch.arange(len(data_list), device=dev),
-                                                torch.tensor(node_counts, device=dev))
+            out.batch = _repeat(torch.arange(len(data_list)), node_counts, dev)
         else:
             out.batch = None
         object.__setattr__(out, "_slices", slices)
