@@ -114,7 +114,8 @@ class GNN_node_efficient(torch.nn.Module):
             x, edge_index, edge_attr, batch = (batched_data.x, batched_data.edge_index, batched_data.edge_attr,
                                                batched_data.batch)
         plan = plan_of(batched_data, Z_TABLE_ROWS)
-        num_graphs = int(batch[-1].item()) + 1
+        ng = batched_data.__dict__.get("_num_graphs") if batched_data is not None else None    # device collate: known on the host
+        num_graphs = ng if ng is not None else int(batch[-1].item()) + 1
         if self.virtual_node:
             vn = self.virtualnode_embedding(torch.zeros(num_graphs, dtype=edge_index.dtype, device=edge_index.device))
         h0 = x if self.skip_node_encoder else self.node_encoder(x)

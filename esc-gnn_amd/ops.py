@@ -513,6 +513,10 @@ def embed_plan(index, dims, known_range=None):
     n, k = index.shape
     dev = index.device
     dims_t = torch.tensor(dims, dtype=torch.int64, device=dev)
+    if known_range is None:                              # the device store leaves the dataset-wide range on the tensors it collates
+        tag = getattr(index, "_esc_known_range", None)
+        if tag is not None and tag[1] == index._version:
+            known_range = tag[0]
     trusted = (known_range is not None and len(known_range[0]) == k == len(dims) and
                all(lo >= 0 and hi < d for lo, hi, d in zip(known_range[0], known_range[1], dims)))
     if not trusted and n and bool(((index < 0) | (index >= dims_t)).any()):        # one check per index tensor, not per lookup

@@ -244,6 +244,9 @@ class DeviceGraphStore(object):
         # the dataset-wide value range of the integer features, valid for exactly these tensors in their current version
         sig = {k: (out[k].data_ptr(), out[k]._version) for k in ("x", "edge_attr") if out[k] is not None}
         object.__setattr__(out, "_esc_int_ranges", (getattr(self, "int_ranges", None) or {}, sig))
+        for k, rng in (getattr(self, "int_ranges", None) or {}).items():     # ... also on the tensors themselves (per-op encoders)
+            if out[k] is not None:
+                out[k]._esc_known_range = (rng, out[k]._version)
         plan._key = plan_key(out, N_COLS)                    # valid as long as nobody swaps or edits the index tensors
         object.__setattr__(out, "_esc_plan", plan)
         has_attr = self.edge_attr_all is not None
