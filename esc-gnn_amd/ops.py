@@ -437,16 +437,17 @@ class _SegmentPool(Function):
 
 def _seg_ptr(batch, size=None):
     """int32 [G+1] segment pointers of a non-decreasing batch vector (esc_plan_csr: integer histogram + scan), built
-    once per batch tensor and cached on it"""
+    once per batch tensor and cached on it (the device collate pre-fills the cache: it knows the node ranges)"""
     from .plan import _csr
-    cached = getattr(batch, "_esc_seg", None)
-    if cached is not None and cached[0] == (batch._version, size):
-        return cached[1]
+    cache = getattr(batch, "_esc_seg", None)
+    key = (batch._version, size)
+    if cache is not None and key in cache:
+        return cache[key]
     n_seg = int(batch[-1].item()) + 1 if (size is None and batch.numel()) else int(size or 0)
     if batch.numel() > 1 and not bool((batch[1:] >= batch[:-1]).all()):
         raise ValueError("segment_pool: batch vector must be sorted")
     seg_ptr = _csr(batch, max(n_seg, 1), want_perm=False)[0][:n_seg + 1]
-    batch._esc_seg = ((batch._version, size), seg_ptr)
+    batch._esc_seg = {key: seg_ptr}
     return seg_ptr
 
 

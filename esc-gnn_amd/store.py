@@ -241,6 +241,7 @@ class DeviceGraphStore(object):
         plan._keepalive = (slab, offs_d, ids_d)
         plan.graph_ptr, plan.num_graphs = offs_d[0].to(torch.int32), B      # node range of every graph (readout pooling)
         object.__setattr__(out, "_num_graphs", B)
+        batch._esc_seg = {(batch._version, None): plan.graph_ptr, (batch._version, B): plan.graph_ptr}   # pooling ops: no rebuild, no read-back
         # the dataset-wide value range of the integer features, valid for exactly these tensors in their current version
         sig = {k: (out[k].data_ptr(), out[k]._version) for k in ("x", "edge_attr") if out[k] is not None}
         object.__setattr__(out, "_esc_int_ranges", (getattr(self, "int_ranges", None) or {}, sig))
