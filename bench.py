@@ -235,6 +235,20 @@ def main():
         linear_one_stream_ms = nv.prof_read("linear")[1] / 5
         nv.call("esc_engine_set_side_stream", 2 if args.streams is None else args.streams)
 
+    # the dominant MFMA kernel on its own: the 128x128x32 tile family that runs the edge-row Linear layers (z_embedding.3 and
+    # conv*.lin, forward and the fused dX+dW launch) — event pairs per launch inside the normal two-stream step
+    edge_gemm = None
+    if not args.no_breakdown and args.path == "engine" and world == 1:
+        nv.prof_reset("gemm_edge")
+        nv.prof_enable("gemm_edge", True)
+        for i in range(5):
+            step(i)
+        torch.cuda.synchronize()
+        nv.prof_enable("gemm_edge", False)
+        per = sorted(nv.prof_read_all("gemm_edge"))
+        if per:
+            edge_gemm = dict(launches_per_step=len(per) / 5, ms_per_step=sum(per) / 5, median_ms=per[len(per) // 2])
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -282,17 +296,28 @@ def main():
     if "linear" in breakdown and breakdown["linear"]["ms_per_step"] > 0:
         fl = linear_flops_per_step(N_avg, E_avg, args.hidden, args.layers)
         tf = fl / (breakdown["linear"]["ms_per_step"] * 1e-3) / 1e12
-        extra["roofline_mfma"] = dict(kernel="esc::dma::gemm_kernel / gemm_dual_kernel + the small-dimension linears (every Linear: fwd+dX+dW), "
-                                             "durations summed while both pipelines share the CUs", bound="mfma",
-                                      achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                                      frac=round(tf / MFMA_F32_PEAK_TF, 4), flops_per_step=int(fl))
+        allin = dict(kernels="every Linear launch of the step (fwd + dX + dW): esc::dma::gemm_kernel / gemm_dual_kernel in all tile shapes + "
+                             "the small-dimension kernels", achieved=round(tf, 2), frac=round(tf / MFMA_F32_PEAK_TF, 4), flops_per_step=int(fl),
+                     note="durations summed inside the two-stream step (kernels of the other pipeline share the CUs)")
         if linear_one_stream_ms:
             tf1 = fl / (linear_one_stream_ms * 1e-3) / 1e12
-            extra["roofline_mfma"].update(
-                achieved_one_stream=round(tf1, 2), frac_one_stream=round(tf1 / MFMA_F32_PEAK_TF, 4),
-                linear_ms_per_step_one_stream=round(linear_one_stream_ms, 4),
-                note="frac: launch durations inside the two-stream step (kernels of the other pipeline share the CUs); "
-                     "frac_one_stream: the same launches of the same step with both pipelines on one stream (each kernel alone)")
+            allin.update(achieved_one_stream=round(tf1, 2), frac_one_stream=round(tf1 / MFMA_F32_PEAK_TF, 4),
+                         linear_ms_per_step_one_stream=round(linear_one_stream_ms, 4))
+        if edge_gemm:
+            # z_embedding.3 + (L-1) H-wide conv*.lin: forward 2*E*H*H each, the fused dX+dW launch 4*E*H*H each
+            n_wide = args.layers                        # 1 + (L - 1)
+            fl_e = 6.0 * E_avg * args.hidden * args.hidden * n_wide
+            tfe = fl_e / (edge_gemm["ms_per_step"] * 1e-3) / 1e12
+            extra["roofline_mfma"] = dict(
+                kernel="esc::dma::gemm_kernel / gemm_dual_kernel <128,128,32, 4 compute + 4 loader waves>: the edge-row Linear launches "
+                       "(z_embedding.3, conv*.lin; forward and fused dX+dW) = %.0f %% of the step's Linear flops" % (100 * fl_e / fl),
+                bound="mfma", achieved=round(tfe, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tfe / MFMA_F32_PEAK_TF, 4),
+                flops_per_step=int(fl_e), launches_per_step=edge_gemm["launches_per_step"],
+                avg_us=round(edge_gemm["ms_per_step"] / edge_gemm["launches_per_step"] * 1e3, 2),
+                clock="event pair per launch inside the two-stream step, mean over 5 steps", all_linear=allin)
+        else:
+            extra["roofline_mfma"] = dict(kernel=allin["kernels"], bound="mfma", achieved=allin["achieved"], peak=MFMA_F32_PEAK_TF,
+                                          unit="TFLOP/s", frac=allin["frac"], flops_per_step=allin["flops_per_step"], all_linear=allin)
     cpu = cpu_baseline(args, graphs) if (args.cpu_seconds > 0 and world == 1) else None   # rank 0, N=1 only
 
     out = {

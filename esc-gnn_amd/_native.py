@@ -137,7 +137,7 @@ _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_
 
 
 KIND = {"agg_fwd": 0, "agg_bwd": 1, "bag_fwd": 2, "bag_bwd": 3, "linear": 4, "collate": 5,
-        "features": 6, "norm": 7}
+        "features": 6, "norm": 7, "gemm_edge": 8}
 
 _lib = None
 

@@ -582,7 +582,7 @@ inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind
   if (e != hipSuccess) return e;
   finish_args<BM, BN>(g);
   const unsigned nwg = (unsigned)(g.ntile_m * g.ntile_n * splits_of(g));
-  esc::launch(kind, kern, dim3(nwg), dim3(C_::NTHR), lds, s, g);
+  esc::launch(BM >= 128 && kind == ESC_K_LINEAR ? ESC_K_GEMM_EDGE : kind, kern, dim3(nwg), dim3(C_::NTHR), lds, s, g);
   return hipSuccess;
 }
 
@@ -600,7 +600,7 @@ inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int k
   finish_args<BM, BN>(a.dw);
   a.n_dx = a.dx.ntile_m * a.dx.ntile_n;
   const unsigned nwg = (unsigned)(a.n_dx + a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw));
-  esc::launch(kind, kern, dim3(nwg), dim3(CX::NTHR), lds, s, a);
+  esc::launch(BM >= 128 && kind == ESC_K_LINEAR ? ESC_K_GEMM_EDGE : kind, kern, dim3(nwg), dim3(CX::NTHR), lds, s, a);
   return hipSuccess;
 }
 

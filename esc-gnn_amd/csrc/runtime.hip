@@ -25,6 +25,7 @@ static ProfState g_prof[ESC_K_COUNT];
 static std::mutex g_prof_mu;
 
 bool prof_slot(int k, hipEvent_t* start, hipEvent_t* stop) {
+  if (k == ESC_K_GEMM_EDGE && !g_prof[k].on) k = ESC_K_LINEAR;       // the edge-row tiles are Linear launches too
   if (k < 0 || k >= ESC_K_COUNT || !g_prof[k].on) return false;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfState& p = g_prof[k];

@@ -33,7 +33,9 @@ const char* esc_last_error(void);         /* message of the last failing call on
 
 /* ---- profiling hook: HIP-event timing of one kernel family on its own launch stream ------ */
 enum { ESC_K_AGG_FWD = 0, ESC_K_AGG_BWD = 1, ESC_K_BAG_FWD = 2, ESC_K_BAG_BWD = 3,
-       ESC_K_LINEAR = 4, ESC_K_COLLATE = 5, ESC_K_FEATURES = 6, ESC_K_NORM = 7, ESC_K_COUNT = 8 };
+       ESC_K_LINEAR = 4, ESC_K_COLLATE = 5, ESC_K_FEATURES = 6, ESC_K_NORM = 7,
+       ESC_K_GEMM_EDGE = 8,   /* the 128-row GEMM tiles (edge-row Linear layers); counted under ESC_K_LINEAR unless enabled itself */
+       ESC_K_COUNT = 9 };
 int esc_prof_enable(int kind, int on);    /* on!=0: bracket every launch of `kind` with events */
 int esc_prof_read(int kind, int64_t* launches, double* total_ms);
 /* per-launch durations (ms) in launch order; returns the number written (<= cap) */
