@@ -49,7 +49,14 @@ p = plain["roofline"]
 print("  untraced run (%s), pairs  : %d launches, average %.2f us -> frac %.3f (median %.2f us, fastest %.2f us)  <- the reported figure; within %.0f %% of the rocprofv3 average" % (sys.argv[3].split("/")[-1], p["launches"], p["avg_us"], p["frac"], p["median_us"], p["min_us"], abs(p["avg_us"] - t) / t * 100))
 gemm = [(n, r) for n, r in rows.items() if "gemm_kernel" in n or "gemm_dual_kernel" in n or "gemm_tile_kernel" in n or "linear_narrow" in n or "small::" in n]
 tot = sum(float(r["TotalDurationNs"]) for _, r in gemm)
-steps = line["steps"] + line["warmup"] + 5 + 7
-fl = line.get("roofline_mfma", {}).get("flops_per_step", 0)
+dual = next((r for n, r in rows.items() if "gemm_dual_kernel<128, 128" in n), None)
+steps = int(dual["Calls"]) // 4 if dual else line["steps"] + line["warmup"] + 17     # 4 edge-row dX+dW launches per step
+mf = line.get("roofline_mfma", {})
+fl = mf.get("all_linear", mf).get("flops_per_step", 0)
+edge = [(n, r) for n, r in rows.items() if ("gemm_kernel" in n or "gemm_dual_kernel" in n) and "128, 128" in n]
+for n, r in edge:
+    print("edge-row tile %s: %d calls, average %.2f us" % (n[:110], int(r["Calls"]), float(r["AverageNs"]) * 1e-3))
+if "avg_us" in mf:
+    print("roofline_mfma (untraced event pairs of the 128x128 tile family): %.2f us per launch, %s launches per step -> %.1f TFLOP/s = %.3f" % (plain["roofline_mfma"]["avg_us"], plain["roofline_mfma"]["launches_per_step"], plain["roofline_mfma"]["achieved"], plain["roofline_mfma"]["frac"]))
 print("all Linear kernels of the traced run: %.1f us per step summed -> %.1f TFLOP/s of the step's %d flops (the traced run includes the one-stream pass)" % (tot / steps * 1e-3, fl / (tot / steps) * 1e-3, fl))
 PY
