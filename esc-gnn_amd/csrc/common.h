@@ -48,6 +48,8 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // the dispatch packet itself — the same begin/end a rocprofv3 kernel trace reports — instead of
 // bracketing the launch with stream events (that adds ~3 us of queue latency to a 7 us kernel).
 bool prof_slot(int kind, hipEvent_t* start, hipEvent_t* stop);
+// ESC_TRACE_LAUNCH=1 (debugging a fault or a hang): every launch is announced on stderr and waited for
+bool trace_launch();
 
 template <typename... KArgs, typename... Args>
 inline void launch(int kind, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s,
@@ -57,6 +59,13 @@ inline void launch(int kind, void (*kernel)(KArgs...), dim3 grid, dim3 block, si
     hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, a, b, 0, static_cast<KArgs>(args)...);
   else
     hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, static_cast<KArgs>(args)...);
+  if (trace_launch()) {
+    const char* name = hipKernelNameRefByPtr(reinterpret_cast<const void*>(kernel), s);
+    fprintf(stderr, "[esc] %s grid (%u,%u,%u) block %u lds %zu stream %p ...", name ? name : "?", grid.x, grid.y, grid.z, block.x, lds, (void*)s);
+    fflush(stderr);
+    const hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+  }
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

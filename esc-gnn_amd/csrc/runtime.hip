@@ -58,6 +58,8 @@ static int g_edge_lds_floor = 52 * 1024;      // 3 edge-GEMM workgroups per CU: 
 int edge_lds_floor() { return g_edge_lds_floor; }
 void set_edge_lds_floor(int bytes) { g_edge_lds_floor = bytes < 0 ? 0 : bytes; }
 
+static const bool g_trace_launch = getenv("ESC_TRACE_LAUNCH") != nullptr && atoi(getenv("ESC_TRACE_LAUNCH")) != 0;
+bool trace_launch() { return g_trace_launch; }
 static int g_bn_bwd_one = getenv("ESC_BN_BWD_ONE") ? atoi(getenv("ESC_BN_BWD_ONE")) : 0;
 bool bn_bwd_one_launch() { return g_bn_bwd_one != 0; }
 void set_bn_bwd_one_launch(int on) { g_bn_bwd_one = on != 0; }

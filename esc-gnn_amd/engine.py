@@ -170,7 +170,33 @@ def install_collective(hidden, device, group=None):
     return True
 
 
-class StepEngine(object):
+class _AddressGuard(object):
+    """The step engines hand the device RAW addresses of the parameters, their gradients and the BatchNorm buffers.
+    An optimiser that re-homes them (FlatAdam moves every parameter and gradient into one bucket),
+    zero_grad(set_to_none=True) or module.to() leaves those addresses dangling — a step would read freed weights and
+    write its gradients over whatever the allocator put there.  Every step therefore compares a few sentinel addresses
+    (first / last parameter and their gradients, first buffer: the realistic changes move all of them) with the ones
+    the descriptor was built from and rebuilds the descriptor when they differ."""
+
+    def _sentinels(self):
+        ps = self._guard_params
+        first, last = ps[0], ps[-1]
+        g0, g1 = first.grad, last.grad
+        bufs = self._guard_buffers
+        return (first.data_ptr(), last.data_ptr(), g0.data_ptr() if g0 is not None else 0,
+                g1.data_ptr() if g1 is not None else 0, bufs[0].data_ptr() if bufs else 0)
+
+    def _guard_arm(self):
+        self._guard_params = list(self.model.parameters())
+        self._guard_buffers = [b for b in self.model.buffers() if b.is_floating_point()]
+        self._guard_sig = self._sentinels()
+
+    def _guard_check(self):
+        if self._sentinels() != self._guard_sig:
+            self.refresh()
+
+
+class StepEngine(_AddressGuard):
     def __init__(self, model):
         if model.graph_pred or model.dropout != 0 or not model.use_cycle:
             raise NotImplementedError("StepEngine covers the run_graphcount configuration "
@@ -195,6 +221,7 @@ class StepEngine(object):
         self._desc = d
         self._keep = [p for p in m.parameters()]
         self._open = None
+        self._guard_arm()
 
     def _batch(self, data, need_y):
         dev = (self.model if isinstance(self, StepEngine) else self).lin1.weight.device
@@ -228,6 +255,7 @@ class StepEngine(object):
     def train_step(self, data, loss_denom=None, return_pred=False, _entry="esc_engine_train_step"):
         """forward + L1 + backward; gradients land in the parameters' .grad (overwritten). Returns loss (0-d)."""
         dev = self.model.lin1.weight.device
+        self._guard_check()
         b, keep = self._batch(data, True)
         ws = self._workspace(b)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -252,6 +280,7 @@ class StepEngine(object):
     @torch.no_grad()
     def predict(self, data):
         dev = self.model.lin1.weight.device
+        self._guard_check()
         b, keep = self._batch(data, False)
         ws = self._workspace(b)
         pred = torch.empty(b.N, dtype=torch.float32, device=dev)
@@ -462,7 +491,7 @@ def _zinc_batch(model, data, need_y):
     return b, (nt, et, y, plan, gptr)
 
 
-class ZincStepEngine(object):
+class ZincStepEngine(_AddressGuard):
     """Training / eval step of zinc_models.NestedGIN_eff as ONE call (esc_zinc_train_step / esc_zinc_predict): same
     parameters, `.grad` slots and BatchNorm buffers as the module, like StepEngine for the counting model."""
 
@@ -477,6 +506,7 @@ class ZincStepEngine(object):
 
     def refresh(self):
         self._desc = describe_zinc(self.model)
+        self._guard_arm()
 
     def _workspace(self, b):
         need = nv.lib().esc_zinc_workspace_floats(ctypes.byref(self._desc), b.N, b.E, b.Z, b.G)
@@ -484,9 +514,16 @@ class ZincStepEngine(object):
             self._ws = torch.empty(int(need * 1.25), dtype=torch.float32, device=self.model.lin1.weight.device)
         return self._ws
 
+    def prepare(self, data):
+        """per-batch plans a prefetching loader can build ahead (harness.prefetched): the collate's own plan is all this
+        model needs"""
+        _zinc_batch(self.model, data, False)
+        return data
+
     def train_step(self, data, loss_denom=None, return_pred=False):
         """forward + L1 over the graphs + backward; gradients land in the parameters' .grad (overwritten)"""
         dev = self.model.lin1.weight.device
+        self._guard_check()
         b, keep = _zinc_batch(self.model, data, True)
         ws = self._workspace(b)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -500,6 +537,7 @@ class ZincStepEngine(object):
     @torch.no_grad()
     def predict(self, data):
         dev = self.model.lin1.weight.device
+        self._guard_check()
         b, keep = _zinc_batch(self.model, data, False)
         ws = self._workspace(b)
         pred = torch.empty(b.G, dtype=torch.float32, device=dev)
@@ -736,7 +774,7 @@ def _drop_seed(model):
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + n) & ((1 << 64) - 1)
 
 
-class OgbStepEngine(object):
+class OgbStepEngine(_AddressGuard):
     """Training / eval step of ogb_mol_gnn.GNN(gnn_type='gin_eff') as ONE call (esc_ogb_train_step / esc_ogb_predict)"""
 
     def __init__(self, model):
@@ -750,6 +788,7 @@ class OgbStepEngine(object):
 
     def refresh(self):
         self._desc = describe_ogb(self.model)
+        self._guard_arm()
 
     def _workspace(self, b):
         need = nv.lib().esc_ogb_workspace_floats(ctypes.byref(self._desc), b.N, b.E, b.Z, b.G, b.atoms.n_entries, b.bonds.n_entries)
@@ -757,9 +796,16 @@ class OgbStepEngine(object):
             self._ws = torch.empty(int(need * 1.25), dtype=torch.float32, device=self.model.graph_pred_linear.weight.device)
         return self._ws
 
+    def prepare(self, data):
+        """builds (and caches on the batch's tensors) every index plan train_step / predict will ask for — the call a
+        prefetching loader makes on its side stream (harness.prefetched)"""
+        _ogb_batch(self.model, data, False, 0)
+        return data
+
     def train_step(self, data, loss_denom=None, return_pred=False):
         """forward + masked BCE-with-logits + backward; gradients land in the parameters' .grad (overwritten)"""
         dev = self.model.graph_pred_linear.weight.device
+        self._guard_check()
         b, keep = _ogb_batch(self.model, data, True, _drop_seed(self.model))
         ws = self._workspace(b)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -773,6 +819,7 @@ class OgbStepEngine(object):
     @torch.no_grad()
     def predict(self, data):
         dev = self.model.graph_pred_linear.weight.device
+        self._guard_check()
         b, keep = _ogb_batch(self.model, data, False, 0)
         ws = self._workspace(b)
         pred = torch.empty((b.G, self.model.num_tasks), dtype=torch.float32, device=dev)

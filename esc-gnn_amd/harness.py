@@ -88,3 +88,49 @@ def sharded_batches(store, batch_size, ctx, shuffle, generator=None):
             continue
         lo, hi = shard_slice(ids.numel(), ctx.rank, ctx.world)
         yield store.collate(ids[lo:hi]), ids.numel()
+
+
+_prefetch_streams = {}
+
+
+def prefetched(batches, device, warm=None):
+    """Iterates `batches` (a generator that collates device batches: sharded_batches, DeviceLoader) ONE ITEM AHEAD on a
+    side HIP stream: batch i+1 is collated — and `warm(item)` builds whatever per-batch index plans the step engine will
+    ask for — while the caller trains on batch i.  This is the role of the reference's DataLoader worker processes
+    (run_ogb_mol.py:229-234, num_workers) with the dataset resident in HBM: the ~60 small gather / counting-sort launches
+    of a molecule batch leave the step's critical path.
+    Ordering: the side stream first waits for everything the caller's stream has been given so far (all of step i-1), so
+    the caching allocator may hand it the blocks of batches that are already dropped; the caller's stream waits for the
+    side stream's event before it touches the batch.  Tensors live in the side stream's pool but are only ever reused
+    behind such a wait."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        for item in batches:
+            if warm is not None:
+                warm(item)
+            yield item
+        return
+    side = _prefetch_streams.get(device)
+    if side is None:
+        side = _prefetch_streams[device] = torch.cuda.Stream(device)
+    it = iter(batches)
+
+    def issue():
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            try:
+                item = next(it)
+            except StopIteration:
+                return None
+            if warm is not None:
+                warm(item)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        return item, ready
+
+    ahead = issue()
+    while ahead is not None:
+        item, ready = ahead
+        torch.cuda.current_stream(device).wait_event(ready)
+        ahead = issue()                                    # queued BEFORE the caller enqueues step i: overlaps it
+        yield item

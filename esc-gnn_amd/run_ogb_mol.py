@@ -90,7 +90,7 @@ def main(argv=None):
     import time
 
     from .datasets import build_feature_dataset, synthetic_ogbmol_graphs
-    from .harness import Context, default_appendix, open_result_dir, sharded_batches
+    from .harness import Context, default_appendix, open_result_dir, prefetched, sharded_batches
     from .metrics import Evaluator
     from .optim import FlatAdam
     from .parallel import broadcast_buffers, broadcast_parameters
@@ -139,7 +139,9 @@ def main(argv=None):
         if engine is not None:
             engine.refresh()                                # (the optimiser owns the gradient buffers: re-read the addresses)
         total = torch.zeros((), device=ctx.device)
-        for data, _ in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
+        warm = (lambda item: engine.prepare(item[0]) if ogb_engine_ready(model, item[0]) else None) if engine is not None else None
+        # the next batch is collated (and its embedding plans built) on a side stream while this one trains
+        for data, _ in prefetched(sharded_batches(stores[0], args.batch_size, ctx, True, gen), ctx.device, warm):
             y = data.y.view(-1, num_tasks)
             if engine is not None and ogb_engine_ready(model, data):
                 if ctx.world > 1:                           # sum-form gradients, ONE all-reduce of grad ++ [labeled targets]

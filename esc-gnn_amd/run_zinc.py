@@ -79,7 +79,7 @@ def main(argv=None):
     import os
     import time
 
-    from .harness import Context, default_appendix, open_result_dir, seed_everything, sharded_batches
+    from .harness import Context, default_appendix, open_result_dir, prefetched, seed_everything, sharded_batches
     from .optim import FlatAdam, ReduceLROnPlateau
     from .parallel import broadcast_buffers, broadcast_parameters
     from .store import DeviceGraphStore
@@ -129,7 +129,8 @@ def main(argv=None):
     def train(epoch):
         model.train()
         loss_all = torch.zeros((), device=ctx.device)
-        for data, n_global in sharded_batches(stores[0], args.batch_size, ctx, True, gen):
+        # the next batch is collated on a side stream while this one trains (harness.prefetched)
+        for data, n_global in prefetched(sharded_batches(stores[0], args.batch_size, ctx, True, gen), ctx.device):
             if engine is not None and zinc_engine_ready(model, data):           # (a 1-graph tail batch takes the per-op path)
                 n_loc = data.y.numel()
                 if ctx.world > 1:                          # sums, one all-reduce of grad ++ [n_local], division inside Adam
