@@ -58,6 +58,9 @@ _FLAGS = [  # same names, types and defaults as the reference CLI (its `type=boo
     ("--pre_visualize", dict(action="store_true", default=False)),
     # additions (not in the reference): size of the synthetic stand-in dataset
     ("--synthetic_graphs", dict(type=int, default=4000, help="molecules; split 80/10/10 by index")),
+    ("--prefetch", dict(action="store_true", default=False,
+                        help="collate the next batch on a side stream (harness.prefetched); measured neutral-to-slower on "
+                             "MI355X at bs=256, see DESIGN.md 4")),
 ]
 
 TASKS = {"ogbg-molhiv": (1, 0.0), "ogbg-molpcba": (128, 0.6)}     # (num_tasks, NaN-label ratio of the stand-in)
@@ -140,8 +143,10 @@ def main(argv=None):
             engine.refresh()                                # (the optimiser owns the gradient buffers: re-read the addresses)
         total = torch.zeros((), device=ctx.device)
         warm = (lambda item: engine.prepare(item[0]) if ogb_engine_ready(model, item[0]) else None) if engine is not None else None
-        # the next batch is collated (and its embedding plans built) on a side stream while this one trains
-        for data, _ in prefetched(sharded_batches(stores[0], args.batch_size, ctx, True, gen), ctx.device, warm):
+        batches = sharded_batches(stores[0], args.batch_size, ctx, True, gen)
+        if args.prefetch:         # the next batch is collated (and its embedding plans built) on a side stream while this one trains
+            batches = prefetched(batches, ctx.device, warm)
+        for data, _ in batches:
             y = data.y.view(-1, num_tasks)
             if engine is not None and ogb_engine_ready(model, data):
                 if ctx.world > 1:                           # sum-form gradients, ONE all-reduce of grad ++ [labeled targets]

@@ -53,6 +53,9 @@ _FLAGS = [  # same names, types and defaults as the reference CLI
     ("--train_only", dict(default=0, type=int)),
     # additions (not in the reference): size of the synthetic stand-in for the absent ZINC.pkl
     ("--synthetic_graphs", dict(type=int, default=12000, help="train+val+test molecules (10:1:1 like ZINC-12k)")),
+    ("--prefetch", dict(action="store_true", default=False,
+                        help="collate the next batch on a side stream (harness.prefetched); measured neutral-to-slower on "
+                             "MI355X at bs=128, see DESIGN.md 4")),
     ("--sync_bn", dict(action="store_true", default=False,
                        help="data parallel only: BatchNorm statistics over all ranks (single-device-equivalent numerics)")),
 ]
@@ -129,8 +132,10 @@ def main(argv=None):
     def train(epoch):
         model.train()
         loss_all = torch.zeros((), device=ctx.device)
-        # the next batch is collated on a side stream while this one trains (harness.prefetched)
-        for data, n_global in prefetched(sharded_batches(stores[0], args.batch_size, ctx, True, gen), ctx.device):
+        batches = sharded_batches(stores[0], args.batch_size, ctx, True, gen)
+        if args.prefetch:         # the next batch is collated on a side stream while this one trains
+            batches = prefetched(batches, ctx.device)
+        for data, n_global in batches:
             if engine is not None and zinc_engine_ready(model, data):           # (a 1-graph tail batch takes the per-op path)
                 n_loc = data.y.numel()
                 if ctx.world > 1:                          # sums, one all-reduce of grad ++ [n_local], division inside Adam

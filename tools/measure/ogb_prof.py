@@ -18,7 +18,17 @@ def step(i):
     b = store.collate(ids[i % len(ids)])
     eng.train_step(b)
     opt.step()
-for i in range(3): step(i)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for i in range(20): step(i)
+if os.environ.get("PREFETCH"):
+    from esc_gnn_amd.harness import prefetched
+    def loop(n):
+        for b in prefetched((store.collate(ids[i % len(ids)]) for i in range(n)), DEV, eng.prepare):
+            eng.train_step(b)
+            opt.step()
+    loop(3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    loop(20)
+else:
+    for i in range(3): step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(20): step(i)
 torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / 20 * 1e3)
