@@ -9,7 +9,7 @@ from ctypes import c_double, c_float, c_int, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libescgnn_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 P, I64, I32, F32 = c_void_p, c_int64, c_int, c_float
 
@@ -23,7 +23,8 @@ class CollateArgs(ctypes.Structure):
                     "c_rank_all", "col_ptr", "col_prefix",
                     "x", "y", "edge_index", "batch", "pos_enc", "pos_index", "pos_batch",
                     "in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst",
-                    "row_ptr", "bag_idx", "bag_val", "col_row", "col_val", "col_col")])
+                    "row_ptr", "bag_idx", "bag_val", "col_row", "col_val", "col_col", "edge_attr_all", "edge_attr")] +
+                [("ea_words", c_int64), ("x_long", c_void_p), ("graph_ptr", c_void_p)])
 
 class BnFuse(ctypes.Structure):
     """mirror of `esc_bn_fuse` (include/escgnn_hip.h)"""
@@ -71,6 +72,8 @@ SIGNATURES = {
     "esc_affine_act_fold": [P, I64, I64, I64, POINTER(BnFold), I32, P, I64, P],
     "esc_plan_csr_scratch": [I64, I64],
     "esc_plan_csr": [P, I64, I64, P, P, P, P, P],
+    "esc_embed_plan_scratch": [I64, I64, I64],
+    "esc_embed_plan": [P, I64, I64, P, P, P, P, P, P, P, P, P, P],
     "esc_tune_set": [I32, I32],
     "esc_debug_gemm_occupancy": [I32],
     "esc_linear_bwd_input": [P, I64, P, I64, I64, I64, I64, P, I64, I32, P],
@@ -129,7 +132,7 @@ SIGNATURES = {
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
-_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_prof_read_all": c_int64,
+_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_embed_plan_scratch": c_int64, "esc_prof_read_all": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64,
         "esc_zinc_workspace_floats": c_int64, "esc_ogb_workspace_floats": c_int64}

@@ -127,7 +127,8 @@ __device__ __forceinline__ void bag_chunk(int chunk, const float* __restrict__ d
       const int col = uniform(c_col[j]);
       const int cb = uniform(col_ptr[col]);
       const int ce = uniform(col_ptr[col + 1]);
-      const int seg_end = max(min(ce, end), j + 1);              // (j + 1: a column pointer that contradicts c_col must not stall the wave)
+      const int seg_end = min(ce, end);
+      if (seg_end <= j) { ++j; continue; }                       // a column pointer that contradicts c_col must not stall the wave
       float acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = 0.f;

@@ -82,7 +82,15 @@ __global__ __launch_bounds__(256) void collate_fill_kernel(esc_collate_args a) {
     a.in_ptr[no + i] = (int)(a.in_ptr_all[n0 + i] - e0 + eo);
     a.out_ptr[no + i] = (int)(a.out_ptr_all[n0 + i] - e0 + eo);
   }
-  for (int64_t i = tid; i < n_g * a.x_dim; i += nthreads) a.x[no * a.x_dim + i] = a.x_all[n0 * a.x_dim + i];
+  if (a.x_long) {                                      // categorical features: exact in fp32, handed out as int64
+    for (int64_t i = tid; i < n_g * a.x_dim; i += nthreads) a.x_long[no * a.x_dim + i] = (int64_t)a.x_all[n0 * a.x_dim + i];
+  } else {
+    for (int64_t i = tid; i < n_g * a.x_dim; i += nthreads) a.x[no * a.x_dim + i] = a.x_all[n0 * a.x_dim + i];
+  }
+  if (a.graph_ptr && tid == 0) {
+    a.graph_ptr[b] = (int)no;
+    if (b == a.B - 1) a.graph_ptr[a.B] = (int)Nt;
+  }
   for (int64_t i = tid; i < y_g * a.y_dim; i += nthreads) a.y[yo * a.y_dim + i] = a.y_all[y0 * a.y_dim + i];
   if (b == a.B - 1 && tid == 0) {
     a.in_ptr[Nt] = (int)Et; a.out_ptr[Nt] = (int)Et; a.row_ptr[Et] = (int)Zt;
@@ -99,6 +107,11 @@ __global__ __launch_bounds__(256) void collate_fill_kernel(esc_collate_args a) {
     a.out_edge[eo + k] = (int)(ko - e0 + eo);
     a.out_dst[eo + k] = (int)(a.edst_all[ko] + no);
     a.row_ptr[eo + k] = (int)(a.row_ptr_all[e0 + k] - z0 + zo);
+  }
+  if (a.edge_attr) {                                   // attribute rows travel with their edges, word by word
+    const uint32_t* __restrict__ src = static_cast<const uint32_t*>(a.edge_attr_all) + e0 * a.ea_words;
+    uint32_t* __restrict__ dst = static_cast<uint32_t*>(a.edge_attr) + eo * a.ea_words;
+    for (int64_t i = tid; i < e_g * a.ea_words; i += nthreads) dst[i] = src[i];
   }
   // ---- bag entries: reference tensors + compact row view + column (CSC) view ----
   for (int64_t j = tid; j < z_g; j += nthreads) {
@@ -141,6 +154,7 @@ int esc_collate_fill(const esc_collate_args* args, void* stream) {
   ESC_REQUIRE(a.B > 0 && a.x_dim >= 0 && a.y_dim >= 0 && a.n_cols > 0, "esc_collate_fill: bad sizes");
   ESC_REQUIRE(a.graph_ids && a.offsets && a.node_ptr && a.edge_ptr && a.nnz_ptr && a.y_ptr, "esc_collate_fill: null index arrays");
   ESC_REQUIRE(a.batch && a.edge_index && a.in_ptr && a.out_ptr && a.row_ptr, "esc_collate_fill: null outputs");
+  ESC_REQUIRE((a.x || a.x_long || a.x_dim == 0) && (!a.edge_attr || (a.edge_attr_all && a.ea_words > 0)), "esc_collate_fill: bad optional outputs");
   hipStream_t s = (hipStream_t)stream;
   esc::launch(ESC_K_COLLATE, collate_fill_kernel, dim3((unsigned)a.B, 8), dim3(256), 0, s, a);
   ESC_CHECK_LAUNCH("esc_collate_fill");

@@ -1062,16 +1062,16 @@ static int backward_ogb(const OgbCtx& z) {
     if (p > 0.f) { ESC_TRY(esc_dropout_bwd(dH, H, N, H, p, w.mask_h, nullptr, 0, y.dT, H, c.s)); dhb = y.dT; }
     ESC_TRY(bn_backward(last ? c0 : c, w.hc, H, nullptr, 0, dhb, H, N, w.bn, q.bn, y.dT, H, y.bn_scratch));
     ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
-    ESC_TRY(bn_backward(c, w.Y0, H2, w.A1, H2, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));
+    ESC_TRY(bn_backward(c, w.Y0, H2, nullptr, 0, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));      // (ReLU mask from the pre-BatchNorm rows: A1 is not re-read)
     ESC_TRY(linear_backward(c, y.dA1, H2, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0));
     // virtual-node update of this layer: vn_{l+1} = dropout(mlp(add_pool(hin) + vn_l)) (+ vn_l)
     bool have_dhin = false;
     if (!last) {
       const float* dVB = dvn_next;
       if (p > 0.f) { ESC_TRY(esc_dropout_bwd(dvn_next, H, G, H, p, w.mask_v, nullptr, 0, y.dG2, H, c.s)); dVB = y.dG2; }
-      ESC_TRY(bn_backward(c, w.V1, H, w.VB, H, dVB, H, G, w.vb1, q.vbn1, y.dG2, H, y.bn_scratch));
+      ESC_TRY(bn_backward(c, w.V1, H, nullptr, 0, dVB, H, G, w.vb1, q.vbn1, y.dG2, H, y.bn_scratch));
       ESC_TRY(linear_backward(c, y.dG2, H, w.VA, H2, nullptr, nullptr, q.vlin1, G, y.dG1, H2, 0));
-      ESC_TRY(bn_backward(c, w.V0, H2, w.VA, H2, y.dG1, H2, G, w.vb0, q.vbn0, y.dG1, H2, y.bn_scratch, H2));
+      ESC_TRY(bn_backward(c, w.V0, H2, nullptr, 0, y.dG1, H2, G, w.vb0, q.vbn0, y.dG1, H2, y.bn_scratch, H2));
       ESC_TRY(linear_backward(c, y.dG1, H2, w.tmp, H, nullptr, nullptr, q.vlin0, G, y.dtmp, H, 0));
       // d vn_l = d tmp (+ d vn_{l+1} through the residual); d hin = broadcast(d tmp) (+ d h_{l+1} through the residual)
       ESC_TRY(esc_dropout_bwd(y.dtmp, H, G, H, 0.f, nullptr, m->residual ? dvn_next : nullptr, H, dvn_cur, H, c.s));
@@ -1101,10 +1101,10 @@ static int backward_ogb(const OgbCtx& z) {
                             m->atom_rows, y.dTcat, y.emb_scratch_n, c.s));
   ESC_TRY(esc_embed_bwd(dvn_next, H, b->zero_idx, G, 1, H, m->vn_dw, c.s));
   // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order)
-  ESC_TRY(bn_backward(ce, y.Yzd, H, y.Zemb, H, y.dZemb, H, E, y.zb1, m->zbn1, y.dYz, H, ce.y.bn_scratch));
+  ESC_TRY(bn_backward(ce, y.Yzd, H, nullptr, 0, y.dZemb, H, E, y.zb1, m->zbn1, y.dYz, H, ce.y.bn_scratch));
   if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dYz, H, E, H, p, y.mask_z1, nullptr, 0, y.dYz, H, ce.s));
   ESC_TRY(linear_backward(ce, y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dA0, H, 0));
-  ESC_TRY(bn_backward(ce, y.Zd, H, y.A0, H, y.dA0, H, E, y.zb0, m->zbn0, y.dA0, H, ce.y.bn_scratch));
+  ESC_TRY(bn_backward(ce, y.Zd, H, nullptr, 0, y.dA0, H, E, y.zb0, m->zbn0, y.dA0, H, ce.y.bn_scratch));
   if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dA0, H, E, H, p, y.mask_z0, nullptr, 0, y.dA0, H, ce.s));
   ESC_TRY(esc_bag_bwd_table_rows(y.dA0, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
                                  m->dz_table, y.bag_scratch, ce.s));

@@ -134,6 +134,43 @@ __global__ __launch_bounds__(256) void plan_count_small_kernel(const int64_t* __
     if (cnt[k]) atomicAdd(&counts[k], cnt[k]);
 }
 
+// ---- sum-of-embeddings plan (AtomEncoder / BondEncoder: ogb_mol_gnn.py:264-282) ---------------------------------------
+// index [n, k] (one id per feature column) -> keys into the k tables laid end to end: key = index + offset[col].  One launch
+// writes the int64 keys the grouping reads, their int32 copy (the bag's index array), the all-ones weights and the row
+// pointers 0, k, 2k, ...; ids outside their table raise the flag (and are clamped so that nothing downstream reads out of
+// range).  A second launch turns the grouping permutation into the CSC view (c_row = entry / k, c_col = key).
+struct EmbedDims { int k; int64_t dim[ESC_MAX_EMBED_COLS]; int64_t off[ESC_MAX_EMBED_COLS]; };
+
+__global__ __launch_bounds__(256) void embed_keys_kernel(const int64_t* __restrict__ index, int64_t n, EmbedDims d,
+                                                         int64_t* __restrict__ key, int* __restrict__ idx32,
+                                                         int* __restrict__ ones, int* __restrict__ row_ptr,
+                                                         int* __restrict__ bad) {
+  const int64_t total = n * d.k;
+  bool any_bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d.k);
+    int64_t v = index[i];
+    if (v < 0 || v >= d.dim[c]) { any_bad = true; v = v < 0 ? 0 : d.dim[c] - 1; }
+    const int64_t kk = v + d.off[c];
+    key[i] = kk;
+    idx32[i] = (int)kk;
+    ones[i] = 1;
+    if (c == 0) row_ptr[i / d.k] = (int)i;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) row_ptr[n] = (int)total;
+  if (any_bad) atomicOr(bad, 1);
+}
+
+// (perm and c_row may be the same buffer: entry i only reads perm[i] before it writes c_row[i])
+__global__ __launch_bounds__(256) void embed_csc_kernel(const int* perm, const int* __restrict__ idx32, int64_t total,
+                                                        int k, int* c_row, int* __restrict__ c_col) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = perm[i];
+    c_row[i] = e / k;
+    c_col[i] = idx32[e];
+  }
+}
+
 }  // namespace esc
 
 using namespace esc;
@@ -181,5 +218,46 @@ int esc_plan_csr(const int64_t* key, int64_t n, int64_t n_keys, int32_t* ptr, in
   }
   return ESC_OK;
 }
+
+int64_t esc_embed_plan_scratch(int64_t n, int64_t k, int64_t rows) {       // int32 words: the int64 keys + the grouping's own scratch
+  return 2 * (n * k + 8) + esc_plan_csr_scratch(n * k, rows > 0 ? rows : 1);
+}
+
+int esc_embed_plan(const int64_t* index, int64_t n, int64_t k, const int64_t* dims, int32_t* idx32, int32_t* ones,
+                   int32_t* row_ptr, int32_t* col_ptr, int32_t* c_row, int32_t* c_col, int32_t* scratch, int32_t* bad_flag,
+                   void* stream) {
+  ESC_REQUIRE(dims && idx32 && ones && row_ptr && col_ptr && c_row && c_col && scratch && bad_flag && (n == 0 || index),
+              "esc_embed_plan: null pointer");
+  ESC_REQUIRE(n >= 0 && k > 0 && k <= ESC_MAX_EMBED_COLS && n * k < (1LL << 31) - 64, "esc_embed_plan: bad sizes n=%ld k=%ld", (long)n, (long)k);
+  EmbedDims d;
+  d.k = (int)k;
+  int64_t rows = 0;
+  for (int c = 0; c < ESC_MAX_EMBED_COLS; ++c) { d.dim[c] = 1; d.off[c] = 0; }
+  for (int c = 0; c < (int)k; ++c) {
+    ESC_REQUIRE(dims[c] > 0 && dims[c] < (1LL << 24), "esc_embed_plan: bad table size");
+    d.dim[c] = dims[c]; d.off[c] = rows; rows += dims[c];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = n * k;
+  int64_t* key = reinterpret_cast<int64_t*>(scratch);                      // (the caller's int32 buffer is 8-byte aligned: see below)
+  ESC_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "esc_embed_plan: scratch must be 8-byte aligned");
+  int32_t* csr_scratch = scratch + 2 * (total + 8);
+  if (hipMemsetAsync(bad_flag, 0, sizeof(int), s) != hipSuccess) { set_error("esc_embed_plan: memset failed"); return ESC_ELAUNCH; }
+  const unsigned blocks = (unsigned)(cdiv(total > 0 ? total : 1, 256) < 2048 ? cdiv(total > 0 ? total : 1, 256) : 2048);
+  esc::launch(ESC_K_COLLATE, embed_keys_kernel, dim3(blocks), dim3(256), 0, s, index, n, d, key, idx32, ones, row_ptr, bad_flag);
+  ESC_CHECK_LAUNCH("esc_embed_plan.keys");
+  // the grouping has its own flag word (it resets it): keys are in range by construction, the caller's flag keeps the id check
+  int32_t* csr_flag = csr_scratch + esc_plan_csr_scratch(total, rows) - 8;
+  const int rc = esc_plan_csr(key, total, rows, col_ptr, c_row /* the permutation, rewritten below */, csr_scratch, csr_flag, stream);
+  if (rc != ESC_OK) return rc;
+  if (total > 0) {
+    // c_row currently holds the permutation; the CSC launch reads it through `perm` and overwrites c_row in place
+    // element by element (entry i only depends on perm[i]) — a separate buffer is not needed
+    esc::launch(ESC_K_COLLATE, embed_csc_kernel, dim3(blocks), dim3(256), 0, s, (const int*)c_row, (const int*)idx32, total, (int)k, c_row, c_col);
+    ESC_CHECK_LAUNCH("esc_embed_plan.csc");
+  }
+  return ESC_OK;
+}
+
 
 }  // extern "C"

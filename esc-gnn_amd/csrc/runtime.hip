@@ -90,7 +90,7 @@ unsigned* tickets(int n) {
 
 extern "C" {
 
-int esc_abi_version(void) { return 2; }   // 2: esc_features_* take sum_nodes_sq; esc_zinc_*, esc_embed_*
+int esc_abi_version(void) { return 3; }   // 2: esc_features_* take sum_nodes_sq; esc_zinc_*, esc_embed_*; 3: esc_collate_args grew (edge_attr, x_long, graph_ptr), esc_embed_plan
 const char* esc_last_error(void) { return esc::g_err; }
 
 int esc_prof_enable(int kind, int on) {

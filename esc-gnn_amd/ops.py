@@ -2,6 +2,8 @@
 include/escgnn_hip.h).  Each Function names the reference call site it replaces.  There is no
 CPU or PyTorch fallback: a CPU tensor raises.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -507,32 +509,41 @@ def embed_plan(index, dims, known_range=None):
     known_range = (per-column minima, per-column maxima) of the DATASET the rows were gathered from (the device store
     computes them once): when they lie inside `dims` the per-batch range check — a device read-back that drains the
     stream — is skipped."""
-    from .plan import _csr
     cache = getattr(index, "_esc_embed", None)
     if cache is not None and cache[0] == (dims, index._version):
         return cache[1]
+    if index.device.type != "cuda":
+        raise RuntimeError("esc_gnn_amd: embedding plans are built on the GPU (got a %s tensor)" % index.device.type)
     n, k = index.shape
     dev = index.device
-    dims_t = torch.tensor(dims, dtype=torch.int64, device=dev)
+    if k != len(dims) or k > 16:
+        raise ValueError("embed_plan: index has %d columns for %d tables (at most 16)" % (k, len(dims)))
     if known_range is None:                              # the device store leaves the dataset-wide range on the tensors it collates
         tag = getattr(index, "_esc_known_range", None)
         if tag is not None and tag[1] == index._version:
             known_range = tag[0]
     trusted = (known_range is not None and len(known_range[0]) == k == len(dims) and
                all(lo >= 0 and hi < d for lo, hi, d in zip(known_range[0], known_range[1], dims)))
-    if not trusted and n and bool(((index < 0) | (index >= dims_t)).any()):        # one check per index tensor, not per lookup
+    idx = index if (index.dtype == torch.int64 and index.is_contiguous()) else index.to(torch.int64).contiguous()
+    rows, total = int(sum(dims)), n * k
+    # ONE int32 slab: idx32 | ones | c_row | c_col | row_ptr | col_ptr | flag | scratch (8-byte aligned start)
+    sizes = [total, total, total, total, n + 1, rows + 1, 2]
+    pad = (-sum(sizes)) % 2
+    need = int(nv.lib().esc_embed_plan_scratch(n, k, rows))
+    slab = torch.empty(sum(sizes) + pad + need, dtype=torch.int32, device=dev)
+    parts, o = [], 0
+    for sz in sizes:
+        parts.append(slab[o:o + sz])
+        o += sz
+    idx32, ones, c_row, c_col, row_ptr, col_ptr, flag = parts
+    scratch = slab[o + pad:]
+    dims_h = (ctypes.c_int64 * k)(*[int(d) for d in dims])
+    nv.call("esc_embed_plan", nv.ptr(idx), n, k, ctypes.addressof(dims_h), nv.ptr(idx32), nv.ptr(ones), nv.ptr(row_ptr),
+            nv.ptr(col_ptr), nv.ptr(c_row), nv.ptr(c_col), nv.ptr(scratch), nv.ptr(flag), nv.stream())
+    if not trusted and total and int(flag[0].item()):    # one check per index tensor, not per lookup (ids known in range: no read-back)
         raise IndexError("embedding index out of range")
-    offs = torch.zeros(k, dtype=torch.int64, device=dev)
-    offs[1:] = torch.cumsum(dims_t, 0)[:-1]
-    flat = (index + offs).reshape(-1)
-    rows = int(sum(dims))
-    flag = torch.zeros(1, dtype=torch.int32, device=dev) if trusted else None    # keys known in range: no read-back
-    col_ptr, order = _csr(flat, rows, bad=flag)      # stable grouping by table row (csrc/plan.hip)
-    order = order.long()
-    plan = dict(idx32=flat.to(torch.int32), row_ptr=torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev),
-                ones=torch.ones(n * k, dtype=torch.int32, device=dev), col_ptr=col_ptr,
-                c_row=torch.div(order, k, rounding_mode="floor").to(torch.int32), c_col=flat[order].to(torch.int32),
-                entries=n * k, rows=rows)
+    plan = dict(idx32=idx32, row_ptr=row_ptr, ones=ones, col_ptr=col_ptr, c_row=c_row, c_col=c_col, entries=total, rows=rows,
+                _slab=slab)
     index._esc_embed = ((dims, index._version), plan)
     return plan
 

@@ -186,7 +186,15 @@ class DeviceGraphStore(object):
         N, E, Z, Y = (int(offs[r, B]) for r in range(4))
         offs_d = offs.to(self.device, non_blocking=True)
         dev, i64, i32, f32 = self.device, torch.int64, torch.int32, torch.float32
-        x = torch.empty((N, self.x_dim), dtype=f32, device=dev)
+        # categorical node features (ZINC / OGB) leave the fill kernel as int64; per-edge attribute rows are gathered by it too
+        x = torch.empty((N, self.x_dim), dtype=i64 if self.x_is_int else f32, device=dev)
+        ea_all = self.edge_attr_all
+        ea_row = 1
+        for d_ in (ea_all.shape[1:] if ea_all is not None else ()):
+            ea_row *= int(d_)
+        ea_fused = ea_all is not None and ea_all.is_contiguous() and ea_row > 0 and (ea_all.element_size() * ea_row) % 4 == 0
+        edge_attr = torch.empty((E,) + tuple(ea_all.shape[1:]), dtype=ea_all.dtype, device=dev) if ea_fused else None
+        graph_ptr = torch.empty(B + 1, dtype=i32, device=dev)
         y = torch.empty((Y, self.y_dim), dtype=f32, device=dev)
         edge_index = torch.empty((2, E), dtype=i64, device=dev)
         batch = torch.empty(N, dtype=i64, device=dev)
@@ -222,12 +230,20 @@ class DeviceGraphStore(object):
                         ("out_dst", out_dst), ("row_ptr", row_ptr), ("bag_idx", bag_idx), ("bag_val", bag_val),
                         ("col_row", col_row), ("col_val", col_val), ("col_col", col_col)):
             setattr(a, name, t.data_ptr())
+        if self.x_is_int:
+            a.x, a.x_long = None, x.data_ptr()
+        if ea_fused:
+            a.edge_attr_all, a.edge_attr = ea_all.data_ptr(), edge_attr.data_ptr()
+            a.ea_words = ea_all.element_size() * ea_row // 4
+        a.graph_ptr = graph_ptr.data_ptr()
         nv.call("esc_collate_fill", ctypes.byref(a), s)
         out = Batch()
         if self.x_is_int:                                    # small categorical ids survive the fp32 round trip exactly
-            x = x.long().view(-1) if self.x_was_1d else x.long()
+            x = x.view(-1) if self.x_was_1d else x
         out.x, out.edge_index = x, edge_index
-        if self.edge_attr_all is not None:                   # per-edge attributes: gather by a device-built index
+        if ea_fused:
+            out.edge_attr = edge_attr
+        elif self.edge_attr_all is not None:                 # (row size not a multiple of 4 bytes) gather by a device-built index
             cnt = (offs_d[1, 1:] - offs_d[1, :-1])
             src0 = self.edge_ptr[ids_d]
             gather = torch.arange(E, device=dev) + torch.repeat_interleave(src0 - offs_d[1, :-1], cnt, output_size=E)   # (output_size: no read-back)
@@ -239,7 +255,7 @@ class DeviceGraphStore(object):
                          col_row=col_row, col_val=col_val, col_col=col_col, num_nodes=N, num_edges=E, nnz=Z,
                          n_cols=N_COLS)
         plan._keepalive = (slab, offs_d, ids_d)
-        plan.graph_ptr, plan.num_graphs = offs_d[0].to(torch.int32), B      # node range of every graph (readout pooling)
+        plan.graph_ptr, plan.num_graphs = graph_ptr, B       # node range of every graph (readout pooling)
         object.__setattr__(out, "_num_graphs", B)
         batch._esc_seg = {(batch._version, None): plan.graph_ptr, (batch._version, B): plan.graph_ptr}   # pooling ops: no rebuild, no read-back
         # the dataset-wide value range of the integer features, valid for exactly these tensors in their current version

@@ -119,6 +119,17 @@ int esc_reduce_sum_jobs(const esc_sum_job* jobs, int count, void* stream);
 int64_t esc_plan_csr_scratch(int64_t n, int64_t n_keys);
 int esc_plan_csr(const int64_t* key, int64_t n, int64_t n_keys, int32_t* ptr, int32_t* perm, int32_t* scratch,
                  int32_t* bad_flag, void* stream);
+/* Bag plan of a sum-of-embeddings lookup (AtomEncoder / BondEncoder, /root/reference/ogb_mol_gnn.py:264-282 and ogb's
+ * BondEncoder): index int64[n, k] holds one id per feature column, the k tables (dims[c] rows each) lie end to end.
+ * Outputs (int32): idx32[n*k] = index + table offset, ones[n*k], row_ptr[n+1] = 0, k, 2k, ... (CSR by output row) and
+ * col_ptr[sum(dims)+1], c_row[n*k], c_col[n*k] (CSC by table row, stable).  bad_flag[0] != 0 afterwards: an id lay
+ * outside its table (it was clamped).  scratch: esc_embed_plan_scratch(n, k, sum(dims)) int32, 8-byte aligned.
+ * 9 launches instead of the ~25 torch index launches of the per-op mirror. */
+#define ESC_MAX_EMBED_COLS 16
+int64_t esc_embed_plan_scratch(int64_t n, int64_t k, int64_t rows);
+int esc_embed_plan(const int64_t* index, int64_t n, int64_t k, const int64_t* dims /* host, k entries */, int32_t* idx32,
+                   int32_t* ones, int32_t* row_ptr, int32_t* col_ptr, int32_t* c_row, int32_t* c_col, int32_t* scratch,
+                   int32_t* bad_flag, void* stream);
 
 /* ---- a-7/a-8/a-9/a-10 dense layers on the matrix cores (exact-fp32 MFMA) -----------------
  * torch.nn.Linear call sites run_graphcount.py:54-121,183-189 (+ GINEConv.lin).
@@ -527,6 +538,12 @@ typedef struct esc_collate_args {
   /* plan outputs */
   int32_t *in_ptr, *in_edge, *in_src, *out_ptr, *out_edge, *out_dst;
   int32_t *row_ptr, *bag_idx, *bag_val, *col_row, *col_val, *col_col;
+  /* optional (ABI 3; NULL / 0 = absent) */
+  const void* edge_attr_all;    /* per-edge attribute rows of the store, ea_words 4-byte words each (edge_attr of ZINC / OGB) */
+  void* edge_attr;              /* [E][ea_words] gathered like edge_index (Batch.from_data_list, batch.py:112-113: no offset) */
+  int64_t ea_words;
+  int64_t* x_long;              /* categorical node features: x written as int64 here instead of float into `x` */
+  int32_t* graph_ptr;           /* [B+1] first node of every graph of the batch (= offsets row 0 as int32) */
 } esc_collate_args;
 /* column bookkeeping of the batch: col_prefix[B][n_cols], col_total[n_cols], col_ptr[n_cols+1] */
 int esc_collate_cols(const int32_t* col_cnt_all, int64_t n_cols, const int64_t* graph_ids, int64_t B,
