@@ -140,6 +140,29 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restric
   y[r * ld_y + c] = v;
 }
 
+// y = dropout_p(act(x * scale_c + shift_c)) + res: a BatchNorm in coefficient form, its activation (0 none, 1 ReLU), the
+// dropout and the residual add of one OGB layer update (ogb_mol_gnn.py:744-755) in ONE pass; element numbering, masks and
+// rounding are those of esc_affine_act followed by esc_dropout_fwd
+__global__ __launch_bounds__(256) void affine_dropout_fwd_kernel(const float* __restrict__ x, int64_t ld_x, int64_t M, int C,
+                                                                 const float* __restrict__ sc, const float* __restrict__ sh, int act,
+                                                                 float p, float scale, unsigned long long seed,
+                                                                 const float* __restrict__ res, int64_t ld_r, float* __restrict__ y,
+                                                                 int64_t ld_y, unsigned char* __restrict__ mask) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const int64_t r = t / C;
+  const int c = (int)(t % C);
+  float v = fmaf(x[r * ld_x + c], sc[c], sh[c]);
+  if (act == 1) v = fmaxf(v, 0.f);
+  if (p > 0.f) {
+    const bool keep = uniform01(seed, (unsigned long long)t) >= p;
+    mask[t] = keep ? 1 : 0;
+    v = keep ? v * scale : 0.f;
+  }
+  if (res) v += res[r * ld_r + c];
+  y[r * ld_y + c] = v;
+}
+
 // dx = dy * mask / (1-p)  (+ add, when given: the other branch of a residual sum)
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, int64_t ld_dy, int64_t M, int C, float p,
                                                           float scale, const unsigned char* __restrict__ mask, const float* __restrict__ add,
@@ -222,6 +245,19 @@ int esc_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int64_t C, float p,
   esc::launch(-1, dropout_fwd_kernel, dim3((unsigned)cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, M, (int)C, p,
               (float)(1.0 / (1.0 - (double)p)), (unsigned long long)seed, res, ld_res, y, ld_y, (unsigned char*)mask);
   ESC_CHECK_LAUNCH("esc_dropout_fwd");
+  return ESC_OK;
+}
+
+int esc_affine_act_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int64_t C, const float* scale, const float* shift, int act,
+                               float p, uint64_t seed, const float* res, int64_t ld_res, float* y, int64_t ld_y, uint8_t* mask,
+                               void* stream) {
+  ESC_REQUIRE(x && y && scale && shift && (p <= 0.f || mask), "esc_affine_act_dropout_fwd: null pointer");
+  ESC_REQUIRE(M >= 0 && C > 0 && C < (1LL << 31) && p >= 0.f && p < 1.f && (act == 0 || act == 1),
+              "esc_affine_act_dropout_fwd: bad arguments (p=%g, act=%d)", (double)p, act);
+  if (M == 0) return ESC_OK;
+  esc::launch(-1, affine_dropout_fwd_kernel, dim3((unsigned)cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, M, (int)C,
+              scale, shift, act, p, (float)(1.0 / (1.0 - (double)p)), (unsigned long long)seed, res, ld_res, y, ld_y, (unsigned char*)mask);
+  ESC_CHECK_LAUNCH("esc_affine_act_dropout_fwd");
   return ESC_OK;
 }
 

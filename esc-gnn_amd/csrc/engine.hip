@@ -903,12 +903,12 @@ static OgbLayout plan_layout_ogb(const esc_ogb_gnn_t* m, int64_t N, int64_t E, i
     OgbLayer& q = y.l[l];
     q.vn = a.take(G * H);
     q.hin = a.take(N * H); q.e = a.take(E * H); q.agg = a.take(N * H);
-    q.Y0 = a.take(N * H2); q.A1 = a.take(N * H2); q.hc = a.take(N * H); q.hb = a.take(N * H);
+    q.Y0 = a.take(N * H2); q.A1 = a.take(N * H2); q.hc = a.take(N * H); q.hb = nullptr;         // (hb is never materialised: BN -> ReLU -> dropout in one pass)
     q.b0 = take_bn(a, H2); q.bn = take_bn(a, H);
     y.h[l + 1] = a.take(N * H);
     if (drop) q.mask_h = take_bytes(a, N * H);
     if (l < L - 1) {
-      q.tmp = a.take(G * H); q.V0 = a.take(G * H2); q.VA = a.take(G * H2); q.V1 = a.take(G * H); q.VB = a.take(G * H);
+      q.tmp = a.take(G * H); q.V0 = a.take(G * H2); q.VA = a.take(G * H2); q.V1 = a.take(G * H); q.VB = nullptr;
       q.vb0 = take_bn(a, H2); q.vb1 = take_bn(a, H);
       if (drop) q.mask_v = take_bytes(a, G * H);
     }
@@ -1012,16 +1012,17 @@ static int forward_ogb(const OgbCtx& z) {
     ESC_TRY(linear_bn(c, w.agg, H, q.lin0, nullptr, nullptr, N, w.Y0, q.bn0, w.b0));
     ESC_TRY(esc_affine_act(w.Y0, H2, N, H2, w.b0.scale, w.b0.shift, 1, w.A1, H2, c.s));
     ESC_TRY(linear_bn(c, w.A1, H2, q.lin1, nullptr, nullptr, N, w.hc, q.bn, w.bn));                                // + batch_norms[l] statistics
-    ESC_TRY(esc_affine_act(w.hc, H, N, H, w.bn.scale, w.bn.shift, l == (int)L - 1 ? 0 : 1, w.hb, H, c.s));         // :744-749
-    ESC_TRY(esc_dropout_fwd(w.hb, H, N, H, p, drop_seed(z, 2 + 2 * l), m->residual ? w.hin : nullptr, H, y.h[l + 1], H, w.mask_h, c.s));
+    // batch_norm -> ReLU (not after the last layer) -> dropout (+ residual), :744-755, as one pass over hc
+    ESC_TRY(esc_affine_act_dropout_fwd(w.hc, H, N, H, w.bn.scale, w.bn.shift, l == (int)L - 1 ? 0 : 1, p, drop_seed(z, 2 + 2 * l),
+                                       m->residual ? w.hin : nullptr, H, y.h[l + 1], H, w.mask_h, c.s));
     if (l < (int)L - 1) {                                                                                            // :757-783
       ESC_TRY(esc_segment_pool_fwd(w.hin, H, b->graph_ptr, G, H, 0, w.tmp, H, c.s));
       ESC_TRY(esc_dropout_fwd(w.tmp, H, G, H, 0.f, 0, w.vn, H, w.tmp, H, nullptr, c.s));                            // + vn
       ESC_TRY(linear_bn(c, w.tmp, H, q.vlin0, nullptr, nullptr, G, w.V0, q.vbn0, w.vb0));
       ESC_TRY(esc_affine_act(w.V0, H2, G, H2, w.vb0.scale, w.vb0.shift, 1, w.VA, H2, c.s));
       ESC_TRY(linear_bn(c, w.VA, H2, q.vlin1, nullptr, nullptr, G, w.V1, q.vbn1, w.vb1));
-      ESC_TRY(esc_affine_act(w.V1, H, G, H, w.vb1.scale, w.vb1.shift, 1, w.VB, H, c.s));
-      ESC_TRY(esc_dropout_fwd(w.VB, H, G, H, p, drop_seed(z, 3 + 2 * l), m->residual ? w.vn : nullptr, H, y.l[l + 1].vn, H, w.mask_v, c.s));
+      ESC_TRY(esc_affine_act_dropout_fwd(w.V1, H, G, H, w.vb1.scale, w.vb1.shift, 1, p, drop_seed(z, 3 + 2 * l),
+                                         m->residual ? w.vn : nullptr, H, y.l[l + 1].vn, H, w.mask_v, c.s));
     }
   }
   ESC_TRY(esc_segment_pool_fwd(y.hL, H, b->graph_ptr, G, H, m->mean_pool, y.pooled, H, c.s));

@@ -443,6 +443,12 @@ int esc_segment_broadcast_add(const float* x, int64_t ld_x, const float* rows, i
  * per element, [M*C]) is written for the backward.  The stream of random numbers is a counter-based hash of (seed,
  * element index) — NOT torch's generator: masks differ from the reference's, their distribution does not.  p == 0 is
  * y = x + res with no mask.  _bwd: dx = dy * mask / (1-p) (+ add). */
+/* y = dropout_p(act(x * scale[c] + shift[c])) (+ res): BatchNorm in coefficient form -> activation (0 none, 1 ReLU) ->
+ * dropout -> residual add of one layer update (/root/reference/ogb_mol_gnn.py:744-755) in one pass; element for element
+ * what esc_affine_act followed by esc_dropout_fwd produce (same masks). */
+int esc_affine_act_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int64_t C, const float* scale, const float* shift, int act,
+                               float p, uint64_t seed, const float* res, int64_t ld_res, float* y, int64_t ld_y, uint8_t* mask,
+                               void* stream);
 int esc_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int64_t C, float p, uint64_t seed, const float* res, int64_t ld_res,
                     float* y, int64_t ld_y, uint8_t* mask, void* stream);
 int esc_dropout_bwd(const float* dy, int64_t ld_dy, int64_t M, int64_t C, float p, const uint8_t* mask, const float* add,

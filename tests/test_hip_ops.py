@@ -496,6 +496,25 @@ def test_dropout_kernels(E, M, C, p):
     assert torch.equal(dx, torch.where(keep, dy * scale, torch.zeros_like(dy)) + res)
 
 
+@pytest.mark.parametrize("M,C,p,act", [(6500, 300, 0.65, 1), (6500, 300, 0.5, 0), (256, 300, 0.0, 1), (1000, 64, 0.1, 1)])
+def test_affine_act_dropout_is_the_two_kernels_in_one(E, M, C, p, act):
+    """esc_affine_act_dropout_fwd == esc_affine_act followed by esc_dropout_fwd, bit for bit (values and keep mask)"""
+    from esc_gnn_amd import _native as nv
+    dev = torch.device("cuda:0")
+    x = torch.randn(M, C, device=dev)
+    sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    res = torch.randn(M, C, device=dev)
+    mid, want, got = (torch.empty(M, C, device=dev) for _ in range(3))
+    m_want, m_got = (torch.zeros(M * C, dtype=torch.uint8, device=dev) for _ in range(2))
+    nv.call("esc_affine_act", nv.ptr(x), C, M, C, nv.ptr(sc), nv.ptr(sh), act, nv.ptr(mid), C, nv.stream())
+    nv.call("esc_dropout_fwd", nv.ptr(mid), C, M, C, p, 77, nv.ptr(res), C, nv.ptr(want), C, nv.ptr(m_want), nv.stream())
+    nv.call("esc_affine_act_dropout_fwd", nv.ptr(x), C, M, C, nv.ptr(sc), nv.ptr(sh), act, p, 77, nv.ptr(res), C, nv.ptr(got), C,
+            nv.ptr(m_got), nv.stream())
+    assert torch.equal(got, want) and torch.equal(m_got, m_want)
+    if act == 1 and p == 0:
+        assert torch.equal(got, torch.relu(torch.addcmul(sh, x, sc)) + res) or torch.allclose(got, torch.relu(x * sc + sh) + res, atol=1e-6)
+
+
 def test_broadcast_add_table_pack_and_accumulating_bag(E):
     """esc_segment_broadcast_add (h + vn[batch]), esc_table_pack / _unpack_grad and esc_bag_fwd_acc against torch"""
     import ctypes
