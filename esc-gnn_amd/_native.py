@@ -119,6 +119,8 @@ SIGNATURES = {
     "esc_zinc_predict": [P, P, P, P, P],
     "esc_segment_broadcast_add": [P, I64, P, I64, P, I64, I64, I64, P, I64, P],
     "esc_dropout_fwd": [P, I64, I64, I64, ctypes.c_float, ctypes.c_uint64, P, I64, P, I64, P, P],
+    "esc_bn_bwd_dropout_ok": [I64, I64, I64, I64],
+    "esc_bn_bwd_dropout": [P, I64, P, I64, I64, I64, P, P, P, P, I32, P, ctypes.c_float, I32, P, I64, P, P, P, P],
     "esc_affine_act_dropout_fwd": [P, I64, I64, I64, P, P, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, P, I64, P, I64, P, P],
     "esc_dropout_bwd": [P, I64, I64, I64, ctypes.c_float, P, P, I64, P, I64, P],
     "esc_table_pack": [P, I64, P, P],

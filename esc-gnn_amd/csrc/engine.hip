@@ -284,6 +284,7 @@ static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's
 // concat slice and the consumers apply relu(x*scale+shift) as they read them — the next layer's aggregate (forward and
 // backward, esc_gine_aggregate_*_affine) and the readout GEMM (prologue over all (L+1)*H columns).  One elementwise launch
 // less per layer on the dependent node chain.  ESC_FUSE_NODE_ACT=0 / esc_engine_set_gemm_stats bit 4 switch it off.
+static int g_fuse_drop_bwd = getenv("ESC_FUSE_DROP_BWD") ? atoi(getenv("ESC_FUSE_DROP_BWD")) : 1;     // dropout backward inside the BatchNorm backward (OGB engine)
 static int g_fuse_node_act = getenv("ESC_FUSE_NODE_ACT") ? atoi(getenv("ESC_FUSE_NODE_ACT")) : 1;
 static int g_fold = getenv("ESC_BN_FOLD") ? atoi(getenv("ESC_BN_FOLD")) : 0;     // 1: both BatchNorms of an MLP merged by their consumers; 2: only the last one (by the affine pass)
 static bool fuse_node_act(const Ctx& c) { return g_fuse_node_act && !g_fold && c.act == 1 && c.y.H >= 64 && c.y.H % 4 == 0 && c.y.cat_scale != nullptr; }
@@ -334,6 +335,30 @@ static int bn_backward(const Ctx& c, const float* X, int64_t ldx, const float* Y
   ESC_TRY(sync_allreduce(c, buf, 2 * C));
   ESC_TRY(esc_bn_sync_coef(buf, C, w.nglob, c.s));
   return esc_bn_bwd_apply(X, ldx, Y, ldy, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, c.act, buf, dX, lddx, c.s);
+}
+
+// BatchNorm(+ReLU) backward next to a dropout: on_output == 0: dY = grad of dropout(act(bn(X))) (mask applied to dY first);
+// on_output == 1: X = dropout(input) (mask applied to the result).  One fused sequence when the operands allow it
+// (esc_bn_bwd_dropout), else the dropout backward as its own pass.  ReLU / no activation only (c.act in {0, 1}).
+static int bn_backward_drop(const Ctx& c, const float* X, int64_t ldx, const float* dY, int64_t lddy, int64_t M, const BnWs& w,
+                            const esc_bn_t& bn, const uint8_t* mask, float p, int on_output, float* dX, int64_t lddx,
+                            float* scratch, int64_t width = 0) {
+  const int64_t C = width > 0 ? width : c.y.H;
+  if (p <= 0.f) return bn_backward(c, X, ldx, nullptr, 0, dY, lddy, M, w, bn, dX, lddx, scratch, width);
+  const bool fused = !sync_on(c) && c.act <= 1 && ldx == C && lddy == C && lddx == C && esc_bn_bwd_dropout_ok(C, ldx, lddy, lddx) &&
+                     ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(dX) |
+                       reinterpret_cast<uintptr_t>(w.mean) | reinterpret_cast<uintptr_t>(w.invstd) | reinterpret_cast<uintptr_t>(bn.gamma) |
+                       reinterpret_cast<uintptr_t>(bn.beta) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(mask) & 3) == 0 && g_fuse_drop_bwd;
+  if (fused)
+    return esc_bn_bwd_dropout(X, ldx, dY, lddy, M, C, w.mean, w.invstd, bn.gamma, bn.beta, c.act, mask, p, on_output, dX, lddx,
+                              bn.dgamma, bn.dbeta, scratch, c.s);
+  if (!on_output) {
+    ESC_TRY(esc_dropout_bwd(dY, lddy, M, C, p, mask, nullptr, 0, dX, lddx, c.s));
+    return bn_backward(c, X, ldx, nullptr, 0, dX, lddx, M, w, bn, dX, lddx, scratch, width);
+  }
+  ESC_TRY(bn_backward(c, X, ldx, nullptr, 0, dY, lddy, M, w, bn, dX, lddx, scratch, width));
+  return esc_dropout_bwd(dX, lddx, M, C, p, mask, nullptr, 0, dX, lddx, c.s);
 }
 
 // Y = X*W^T + b followed by BatchNorm coefficient computation (training: batch statistics; eval: running ones)
@@ -1059,18 +1084,14 @@ static int backward_ogb(const OgbCtx& z) {
     const OgbLayer& w = y.l[l];
     const bool last = l == (int)L - 1;
     // h_{l+1} = dropout(hb) (+ hin)
-    const float* dhb = dH;
-    if (p > 0.f) { ESC_TRY(esc_dropout_bwd(dH, H, N, H, p, w.mask_h, nullptr, 0, y.dT, H, c.s)); dhb = y.dT; }
-    ESC_TRY(bn_backward(last ? c0 : c, w.hc, H, nullptr, 0, dhb, H, N, w.bn, q.bn, y.dT, H, y.bn_scratch));
+    ESC_TRY(bn_backward_drop(last ? c0 : c, w.hc, H, dH, H, N, w.bn, q.bn, w.mask_h, p, 0, y.dT, H, y.bn_scratch));
     ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
     ESC_TRY(bn_backward(c, w.Y0, H2, nullptr, 0, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));      // (ReLU mask from the pre-BatchNorm rows: A1 is not re-read)
     ESC_TRY(linear_backward(c, y.dA1, H2, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0));
     // virtual-node update of this layer: vn_{l+1} = dropout(mlp(add_pool(hin) + vn_l)) (+ vn_l)
     bool have_dhin = false;
     if (!last) {
-      const float* dVB = dvn_next;
-      if (p > 0.f) { ESC_TRY(esc_dropout_bwd(dvn_next, H, G, H, p, w.mask_v, nullptr, 0, y.dG2, H, c.s)); dVB = y.dG2; }
-      ESC_TRY(bn_backward(c, w.V1, H, nullptr, 0, dVB, H, G, w.vb1, q.vbn1, y.dG2, H, y.bn_scratch));
+      ESC_TRY(bn_backward_drop(c, w.V1, H, dvn_next, H, G, w.vb1, q.vbn1, w.mask_v, p, 0, y.dG2, H, y.bn_scratch));
       ESC_TRY(linear_backward(c, y.dG2, H, w.VA, H2, nullptr, nullptr, q.vlin1, G, y.dG1, H2, 0));
       ESC_TRY(bn_backward(c, w.V0, H2, nullptr, 0, y.dG1, H2, G, w.vb0, q.vbn0, y.dG1, H2, y.bn_scratch, H2));
       ESC_TRY(linear_backward(c, y.dG1, H2, w.tmp, H, nullptr, nullptr, q.vlin0, G, y.dtmp, H, 0));
@@ -1102,11 +1123,9 @@ static int backward_ogb(const OgbCtx& z) {
                             m->atom_rows, y.dTcat, y.emb_scratch_n, c.s));
   ESC_TRY(esc_embed_bwd(dvn_next, H, b->zero_idx, G, 1, H, m->vn_dw, c.s));
   // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order)
-  ESC_TRY(bn_backward(ce, y.Yzd, H, nullptr, 0, y.dZemb, H, E, y.zb1, m->zbn1, y.dYz, H, ce.y.bn_scratch));
-  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dYz, H, E, H, p, y.mask_z1, nullptr, 0, y.dYz, H, ce.s));
+  ESC_TRY(bn_backward_drop(ce, y.Yzd, H, y.dZemb, H, E, y.zb1, m->zbn1, y.mask_z1, p, 1, y.dYz, H, ce.y.bn_scratch));
   ESC_TRY(linear_backward(ce, y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dA0, H, 0));
-  ESC_TRY(bn_backward(ce, y.Zd, H, nullptr, 0, y.dA0, H, E, y.zb0, m->zbn0, y.dA0, H, ce.y.bn_scratch));
-  if (p > 0.f) ESC_TRY(esc_dropout_bwd(y.dA0, H, E, H, p, y.mask_z0, nullptr, 0, y.dA0, H, ce.s));
+  ESC_TRY(bn_backward_drop(ce, y.Zd, H, y.dA0, H, E, y.zb0, m->zbn0, y.mask_z0, p, 1, y.dA0, H, ce.y.bn_scratch));
   ESC_TRY(esc_bag_bwd_table_rows(y.dA0, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
                                  m->dz_table, y.bag_scratch, ce.s));
   if (es.ok && !edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));

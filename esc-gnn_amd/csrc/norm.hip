@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel_v4(const float* __restr
 // load makes hipcc branch and wait per element, which is what kept the scalar kernel at ~1 TB/s).
 // The four waves of a workgroup add their sums through LDS (fixed order) into ONE slot per workgroup, and the
 // workgroup that finishes last (grid_last_block) folds the slots into dgamma / dbeta / coef: no finalize launch.
-template <int ACT, bool HAS_Y>
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __restrict__ X, int64_t ldx,
+// DROP: dY is the gradient of dropout(act(bn(X))): g = dY * keep / (1-p) first (dmask: one byte per element, [M][C]) —
+// the dropout backward of an OGB layer update (ogb_mol_gnn.py:750-755) without its own pass over the rows
+template <int ACT, bool HAS_Y, bool DROP>
+__device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ X, int64_t ldx,
                                                                 const float* __restrict__ Y, int64_t ldy,
                                                                 const float* __restrict__ dY, int64_t ldg, int M,
                                                                 int C, const float* __restrict__ mean,
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __r
                                                                 const float* __restrict__ beta,
                                                                 float2* partial, unsigned* tickets,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                float2* __restrict__ coef) {
+                                                                float2* __restrict__ coef,
+                                                                const unsigned char* __restrict__ dmask, float dscale) {
   ESC_PRIO();
   constexpr int relu = ACT;
   __shared__ float4 sh[3][2][64];
@@ -133,6 +136,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __r
 #pragma unroll 4
     for (int r = slot; r < M; r += P) {
       float4 g = *reinterpret_cast<const float4*>(dY + (size_t)r * ldg + c);
+      if constexpr (DROP) {
+        const uchar4 mk = *reinterpret_cast<const uchar4*>(dmask + (size_t)r * C + c);
+        g.x = mk.x ? g.x * dscale : 0.f; g.y = mk.y ? g.y * dscale : 0.f; g.z = mk.z ? g.z * dscale : 0.f; g.w = mk.w ? g.w * dscale : 0.f;
+      }
       const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
       const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
       if constexpr (ACT != 0) {
@@ -187,6 +194,23 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __r
   if (dgamma) dgamma[col] = (float)t2;
   if (dbeta) dbeta[col] = (float)t1;
   coef[col] = make_float2((float)(t1 / M), (float)(t2 / M));
+}
+
+template <int ACT, bool HAS_Y>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel_v4(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y, int64_t ldy,
+                                                                const float* __restrict__ dY, int64_t ldg, int M, int C,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float2* partial, unsigned* tickets, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, float2* __restrict__ coef) {
+  bn_bwd_partial_body<ACT, HAS_Y, false>(X, ldx, Y, ldy, dY, ldg, M, C, mean, invstd, gamma, beta, partial, tickets, dgamma, dbeta, coef, nullptr, 0.f);
+}
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_partial_drop_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldg,
+                                                                  int M, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float2* partial,
+                                                                  const unsigned char* __restrict__ dmask, float dscale) {
+  bn_bwd_partial_body<ACT, false, true>(X, ldx, nullptr, 0, dY, ldg, M, C, mean, invstd, gamma, beta, partial, nullptr, nullptr, nullptr, nullptr, dmask, dscale);
 }
 
 // one wave per column: lanes own slots lane, lane+64, ... then a shuffle-tree merge (fixed order)
@@ -380,8 +404,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // every wave adds the (few) slots of its four columns itself, in slot order with fp64 accumulators like the finalize
 // kernel; the first row block also writes dgamma / dbeta.  Node-sized BatchNorms only (<= 32 slots): a dependent launch
 // costs more than 64 extra loads per lane.
-template <int ACT, bool HAS_Y, bool FOLD = false>
-__global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict__ X, int64_t ldx,
+// DROP_IN: as in the partial kernel (g = dY * keep / (1-p)); DROP_OUT: X itself was dropout(input), so the result is
+// multiplied by ITS keep mask / (1-p) on the way out (z_embedding's Dropout -> BatchNorm order, ogb_mol_gnn.py:638-645)
+template <int ACT, bool HAS_Y, bool FOLD, bool DROP_IN, bool DROP_OUT>
+__device__ __forceinline__ void bn_bwd_apply_rows_body(const float* __restrict__ X, int64_t ldx,
                                                          const float* __restrict__ Y, int64_t ldy,
                                                          const float* __restrict__ dY, int64_t ldg, int M, int C,
                                                          const float* __restrict__ mean,
@@ -389,8 +415,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          const float2* __restrict__ coef,
-                                                         float* __restrict__ dX, int64_t ldd, int fold_slots = 0,
-                                                         float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
+                                                         float* __restrict__ dX, int64_t ldd, int fold_slots,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         const unsigned char* __restrict__ dmask, float dscale) {
   ESC_PRIO();
   constexpr int relu = ACT;
   const int c = (blockIdx.x * 64 + lane_id()) * 4;
@@ -423,6 +450,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
   for (int r = slot; r < M; r += P) {
     const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
     float4 g = *reinterpret_cast<const float4*>(dY + (size_t)r * ldg + c);
+    uchar4 mk = make_uchar4(1, 1, 1, 1);
+    if constexpr (DROP_IN || DROP_OUT) mk = *reinterpret_cast<const uchar4*>(dmask + (size_t)r * C + c);
+    if constexpr (DROP_IN) {
+      g.x = mk.x ? g.x * dscale : 0.f; g.y = mk.y ? g.y * dscale : 0.f; g.z = mk.z ? g.z * dscale : 0.f; g.w = mk.w ? g.w * dscale : 0.f;
+    }
     const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
     if constexpr (ACT != 0) {
       if constexpr (HAS_Y) {
@@ -435,10 +467,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict
       }
     }
     // same expression as bn_bwd_apply_kernel: gamma * invstd * (g - k.x - xhat * k.y)
-    *reinterpret_cast<float4*>(dX + (size_t)r * ldd + c) =
-        make_float4(a.x * (g.x - k01.x - xh.x * k01.y), a.y * (g.y - k01.z - xh.y * k01.w),
-                    a.z * (g.z - k23.x - xh.z * k23.y), a.w * (g.w - k23.z - xh.w * k23.w));
+    float4 o = make_float4(a.x * (g.x - k01.x - xh.x * k01.y), a.y * (g.y - k01.z - xh.y * k01.w),
+                           a.z * (g.z - k23.x - xh.z * k23.y), a.w * (g.w - k23.z - xh.w * k23.w));
+    if constexpr (DROP_OUT) {
+      o.x = mk.x ? o.x * dscale : 0.f; o.y = mk.y ? o.y * dscale : 0.f; o.z = mk.z ? o.z * dscale : 0.f; o.w = mk.w ? o.w * dscale : 0.f;
+    }
+    *reinterpret_cast<float4*>(dX + (size_t)r * ldd + c) = o;
   }
+}
+
+template <int ACT, bool HAS_Y, bool FOLD = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y, int64_t ldy,
+                                                         const float* __restrict__ dY, int64_t ldg, int M, int C,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float2* __restrict__ coef, float* __restrict__ dX, int64_t ldd,
+                                                         int fold_slots, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  bn_bwd_apply_rows_body<ACT, HAS_Y, FOLD, false, false>(X, ldx, Y, ldy, dY, ldg, M, C, mean, invstd, gamma, beta, coef, dX, ldd, fold_slots, dgamma, dbeta, nullptr, 0.f);
+}
+template <int ACT, bool DROP_IN, bool DROP_OUT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_drop(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldg,
+                                                              int M, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float2* __restrict__ coef, float* __restrict__ dX, int64_t ldd,
+                                                              const unsigned char* __restrict__ dmask, float dscale) {
+  bn_bwd_apply_rows_body<ACT, false, false, DROP_IN, DROP_OUT>(X, ldx, nullptr, 0, dY, ldg, M, C, mean, invstd, gamma, beta, coef, dX, ldd, 0, nullptr, nullptr, dmask, dscale);
 }
 
 __global__ __launch_bounds__(256) void affine_act_rows(const float* __restrict__ X, int64_t ldx, int M, int C,
@@ -980,6 +1033,50 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
   int rc = bn_bwd_reduce(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, M, true, dgamma, dbeta, partial, coef, s);
   if (rc != ESC_OK) return rc;
   return bn_bwd_apply_impl(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, coef, dX, ld_dx, s);
+}
+
+int esc_bn_bwd_dropout_ok(int64_t C, int64_t ld_x, int64_t ld_dy, int64_t ld_dx) {
+  return C % 4 == 0 && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0;
+}
+
+int esc_bn_bwd_dropout(const float* X, int64_t ld_x, const float* dY, int64_t ld_dy, int64_t M, int64_t C, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta, int relu, const uint8_t* mask, float p,
+                       int mask_on_output, float* dX, int64_t ld_dx, float* dgamma, float* dbeta, float* scratch, void* stream) {
+  ESC_REQUIRE(X && dY && dX && mean && invstd && scratch && mask, "esc_bn_bwd_dropout: null pointer");
+  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && M < (1LL << 31) && p > 0.f && p < 1.f && (relu == 0 || relu == 1),
+              "esc_bn_bwd_dropout: bad arguments");
+  float2* partial = (float2*)scratch;
+  float2* coef = partial + (size_t)NORM_ROWBLOCKS * 4 * C;
+  ESC_REQUIRE(esc_bn_bwd_dropout_ok(C, ld_x, ld_dy, ld_dx) && aligned16(X) && aligned16(dY) && aligned16(dX) && aligned16(mean) &&
+              aligned16(invstd) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && aligned16(partial) && aligned16(coef) &&
+              (reinterpret_cast<uintptr_t>(mask) & 3) == 0, "esc_bn_bwd_dropout: operands must be 16-byte aligned with widths a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const float dscale = (float)(1.0 / (1.0 - (double)p));
+  const int rb = rowblocks(M, true, true);
+  const dim3 grid((unsigned)cdiv(C, 256), rb);
+  const unsigned char* mk = (const unsigned char*)mask;
+  if (mask_on_output) {        // the sums are those of the plain BatchNorm backward
+    const float* noy = nullptr; unsigned* tk = nullptr; float* nof = nullptr; float2* noc = nullptr;
+    if (relu) esc::launch(ESC_K_NORM, bn_bwd_partial_kernel_v4<1, false>, grid, dim3(256), 0, s, X, ld_x, noy, (int64_t)0, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial, tk, nof, nof, noc);
+    else      esc::launch(ESC_K_NORM, bn_bwd_partial_kernel_v4<0, false>, grid, dim3(256), 0, s, X, ld_x, noy, (int64_t)0, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial, tk, nof, nof, noc);
+  } else {
+    if (relu) esc::launch(ESC_K_NORM, bn_bwd_partial_drop_kernel<1>, grid, dim3(256), 0, s, X, ld_x, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial, mk, dscale);
+    else      esc::launch(ESC_K_NORM, bn_bwd_partial_drop_kernel<0>, grid, dim3(256), 0, s, X, ld_x, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, partial, mk, dscale);
+  }
+  ESC_CHECK_LAUNCH("esc_bn_bwd_dropout.partial");
+  esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, s, (const float2*)partial, (int)M, (int)C, rb, dgamma, dbeta, coef);
+  ESC_CHECK_LAUNCH("esc_bn_bwd_dropout.finalize");
+  const dim3 agrid((unsigned)cdiv(C, 256), (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048));
+  const float2* kc = coef;
+  if (mask_on_output) {
+    if (relu) esc::launch(ESC_K_NORM, bn_bwd_apply_rows_drop<1, false, true>, agrid, dim3(256), 0, s, X, ld_x, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, kc, dX, ld_dx, mk, dscale);
+    else      esc::launch(ESC_K_NORM, bn_bwd_apply_rows_drop<0, false, true>, agrid, dim3(256), 0, s, X, ld_x, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, kc, dX, ld_dx, mk, dscale);
+  } else {
+    if (relu) esc::launch(ESC_K_NORM, bn_bwd_apply_rows_drop<1, true, false>, agrid, dim3(256), 0, s, X, ld_x, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, kc, dX, ld_dx, mk, dscale);
+    else      esc::launch(ESC_K_NORM, bn_bwd_apply_rows_drop<0, true, false>, agrid, dim3(256), 0, s, X, ld_x, dY, ld_dy, (int)M, (int)C, mean, invstd, gamma, beta, kc, dX, ld_dx, mk, dscale);
+  }
+  ESC_CHECK_LAUNCH("esc_bn_bwd_dropout.apply");
+  return ESC_OK;
 }
 
 int esc_bn_bwd_sums(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,

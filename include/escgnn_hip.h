@@ -273,6 +273,17 @@ int esc_bn_bwd(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const
                int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
                const float* gamma, const float* beta, int relu, float* dX, int64_t ld_dx,
                float* dgamma, float* dbeta, float* scratch, void* stream);
+/* BatchNorm(+ReLU) backward with a dropout backward folded in (OGB layer updates, /root/reference/ogb_mol_gnn.py:638-645,
+ * :744-755): no Y variant (the ReLU mask comes from the pre-BatchNorm rows), relu in {0, 1}, mask = the keep bytes [M][C] of
+ * esc_dropout_fwd / esc_affine_act_dropout_fwd, p its rate.
+ *   mask_on_output == 0: dY is the gradient of dropout(act(bn(X))) — g = dY * keep / (1-p) before everything else;
+ *   mask_on_output == 1: X itself was dropout(input) — the result dX is multiplied by keep / (1-p).
+ * Same three launches and the same arithmetic as esc_dropout_bwd followed by esc_bn_bwd (or the reverse).  Needs
+ * esc_bn_bwd_dropout_ok(...) (widths and leading dimensions multiples of 4) and 16-byte aligned operands. */
+int esc_bn_bwd_dropout_ok(int64_t C, int64_t ld_x, int64_t ld_dy, int64_t ld_dx);
+int esc_bn_bwd_dropout(const float* X, int64_t ld_x, const float* dY, int64_t ld_dy, int64_t M, int64_t C, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta, int relu, const uint8_t* mask, float p,
+                       int mask_on_output, float* dX, int64_t ld_dx, float* dgamma, float* dbeta, float* scratch, void* stream);
 /* The two halves of esc_bn_bwd for a BatchNorm whose statistics span several ranks (SyncBN):
  * _sums writes sums[c] = (sum g, sum g*xhat) over the LOCAL rows (float2[C]; g = dY * act'), with mean / invstd the
  * GLOBAL statistics, plus the local dgamma / dbeta; the caller all-reduces `sums`, divides by the global row count

@@ -515,6 +515,48 @@ def test_affine_act_dropout_is_the_two_kernels_in_one(E, M, C, p, act):
         assert torch.equal(got, torch.relu(torch.addcmul(sh, x, sc)) + res) or torch.allclose(got, torch.relu(x * sc + sh) + res, atol=1e-6)
 
 
+@pytest.mark.parametrize("M,C,p,relu,on_output", [(6500, 300, 0.65, 1, 0), (6500, 300, 0.5, 0, 0), (20000, 300, 0.65, 1, 1),
+                                                  (256, 600, 0.3, 1, 0), (1000, 64, 0.1, 1, 1)])
+def test_bn_backward_with_dropout_folded_in(E, M, C, p, relu, on_output):
+    """esc_bn_bwd_dropout == esc_dropout_bwd -> esc_bn_bwd (mask on the incoming gradient) or esc_bn_bwd -> esc_dropout_bwd
+    (mask on the result), bit for bit: dX, dgamma, dbeta"""
+    from esc_gnn_amd import _native as nv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + C)
+    x = torch.randn(M, C, device=dev) * 2 + 0.5
+    dy = torch.randn(M, C, device=dev)
+    gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3
+    mean, var = x.mean(0).contiguous(), x.var(0, unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
+    mask = (torch.rand(M * C, device=dev) >= p).to(torch.uint8)
+    scratch = torch.empty(nv.lib().esc_bn_scratch(C), device=dev)
+    assert nv.lib().esc_bn_bwd_dropout_ok(C, C, C, C)
+
+    def run(fused):
+        dx, dg, db = torch.empty(M, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        if fused:
+            nv.call("esc_bn_bwd_dropout", nv.ptr(x), C, nv.ptr(dy), C, M, C, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+                    relu, nv.ptr(mask), p, on_output, nv.ptr(dx), C, nv.ptr(dg), nv.ptr(db), nv.ptr(scratch), nv.stream())
+        elif on_output:
+            nv.call("esc_bn_bwd", nv.ptr(x), C, None, 0, nv.ptr(dy), C, M, C, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+                    relu, nv.ptr(dx), C, nv.ptr(dg), nv.ptr(db), nv.ptr(scratch), nv.stream())
+            nv.call("esc_dropout_bwd", nv.ptr(dx), C, M, C, p, nv.ptr(mask), None, 0, nv.ptr(dx), C, nv.stream())
+        else:
+            t = torch.empty(M, C, device=dev)
+            nv.call("esc_dropout_bwd", nv.ptr(dy), C, M, C, p, nv.ptr(mask), None, 0, nv.ptr(t), C, nv.stream())
+            nv.call("esc_bn_bwd", nv.ptr(x), C, None, 0, nv.ptr(t), C, M, C, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+                    relu, nv.ptr(dx), C, nv.ptr(dg), nv.ptr(db), nv.ptr(scratch), nv.stream())
+        return dx, dg, db
+
+    got, want = run(True), run(False)
+    for a, b, name in zip(got, want, ("dX", "dgamma", "dbeta")):
+        # (the two-step form may take the node-sized one-workgroup-finalize route: same sums, possibly another order)
+        assert torch.equal(a, b) or torch.allclose(a, b, rtol=2e-6, atol=2e-6 * float(b.abs().max())), name
+    keep = mask.view(M, C).bool()
+    if on_output:
+        assert float(got[0][~keep].abs().max()) == 0
+
+
 def test_broadcast_add_table_pack_and_accumulating_bag(E):
     """esc_segment_broadcast_add (h + vn[batch]), esc_table_pack / _unpack_grad and esc_bag_fwd_acc against torch"""
     import ctypes
