@@ -284,6 +284,7 @@ static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's
 // concat slice and the consumers apply relu(x*scale+shift) as they read them — the next layer's aggregate (forward and
 // backward, esc_gine_aggregate_*_affine) and the readout GEMM (prologue over all (L+1)*H columns).  One elementwise launch
 // less per layer on the dependent node chain.  ESC_FUSE_NODE_ACT=0 / esc_engine_set_gemm_stats bit 4 switch it off.
+static int g_ogb_prologue = getenv("ESC_OGB_PROLOGUE") ? atoi(getenv("ESC_OGB_PROLOGUE")) : 1;        // OGB node MLP: BN+ReLU of the hidden layer in lin1's GEMM prologue
 static int g_fuse_drop_bwd = getenv("ESC_FUSE_DROP_BWD") ? atoi(getenv("ESC_FUSE_DROP_BWD")) : 1;     // dropout backward inside the BatchNorm backward (OGB engine)
 static int g_fuse_node_act = getenv("ESC_FUSE_NODE_ACT") ? atoi(getenv("ESC_FUSE_NODE_ACT")) : 1;
 static int g_fold = getenv("ESC_BN_FOLD") ? atoi(getenv("ESC_BN_FOLD")) : 0;     // 1: both BatchNorms of an MLP merged by their consumers; 2: only the last one (by the affine pass)
@@ -1035,8 +1036,12 @@ static int forward_ogb(const OgbCtx& z) {
       ESC_TRY(edge_term(l + ahead));
     }
     ESC_TRY(linear_bn(c, w.agg, H, q.lin0, nullptr, nullptr, N, w.Y0, q.bn0, w.b0));
-    ESC_TRY(esc_affine_act(w.Y0, H2, N, H2, w.b0.scale, w.b0.shift, 1, w.A1, H2, c.s));
-    ESC_TRY(linear_bn(c, w.A1, H2, q.lin1, nullptr, nullptr, N, w.hc, q.bn, w.bn));                                // + batch_norms[l] statistics
+    if (g_ogb_prologue) {                       // relu(bn(Y0)) applied to the staged operand of lin1: A1 is never written
+      ESC_TRY(linear_bn(c, w.Y0, H2, q.lin1, w.b0.scale, w.b0.shift, N, w.hc, q.bn, w.bn));
+    } else {
+      ESC_TRY(esc_affine_act(w.Y0, H2, N, H2, w.b0.scale, w.b0.shift, 1, w.A1, H2, c.s));
+      ESC_TRY(linear_bn(c, w.A1, H2, q.lin1, nullptr, nullptr, N, w.hc, q.bn, w.bn));                              // + batch_norms[l] statistics
+    }
     // batch_norm -> ReLU (not after the last layer) -> dropout (+ residual), :744-755, as one pass over hc
     ESC_TRY(esc_affine_act_dropout_fwd(w.hc, H, N, H, w.bn.scale, w.bn.shift, l == (int)L - 1 ? 0 : 1, p, drop_seed(z, 2 + 2 * l),
                                        m->residual ? w.hin : nullptr, H, y.h[l + 1], H, w.mask_h, c.s));
@@ -1085,7 +1090,8 @@ static int backward_ogb(const OgbCtx& z) {
     const bool last = l == (int)L - 1;
     // h_{l+1} = dropout(hb) (+ hin)
     ESC_TRY(bn_backward_drop(last ? c0 : c, w.hc, H, dH, H, N, w.bn, q.bn, w.mask_h, p, 0, y.dT, H, y.bn_scratch));
-    ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
+    if (g_ogb_prologue) ESC_TRY(linear_backward(c, y.dT, H, w.Y0, H2, w.b0.scale, w.b0.shift, q.lin1, N, y.dA1, H2, 0));
+    else                ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
     ESC_TRY(bn_backward(c, w.Y0, H2, nullptr, 0, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));      // (ReLU mask from the pre-BatchNorm rows: A1 is not re-read)
     ESC_TRY(linear_backward(c, y.dA1, H2, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0));
     // virtual-node update of this layer: vn_{l+1} = dropout(mlp(add_pool(hin) + vn_l)) (+ vn_l)
