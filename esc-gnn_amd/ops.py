@@ -538,8 +538,13 @@ def embed_plan(index, dims, known_range=None):
     idx32, ones, c_row, c_col, row_ptr, col_ptr, flag = parts
     scratch = slab[o + pad:]
     dims_h = (ctypes.c_int64 * k)(*[int(d) for d in dims])
-    nv.call("esc_embed_plan", nv.ptr(idx), n, k, ctypes.addressof(dims_h), nv.ptr(idx32), nv.ptr(ones), nv.ptr(row_ptr),
-            nv.ptr(col_ptr), nv.ptr(c_row), nv.ptr(c_col), nv.ptr(scratch), nv.ptr(flag), nv.stream())
+    if total == 0:                                       # nothing to look up: empty entry arrays, all-zero pointers
+        row_ptr.zero_()
+        col_ptr.zero_()
+        flag.zero_()
+    else:
+        nv.call("esc_embed_plan", nv.ptr(idx), n, k, ctypes.addressof(dims_h), nv.ptr(idx32), nv.ptr(ones), nv.ptr(row_ptr),
+                nv.ptr(col_ptr), nv.ptr(c_row), nv.ptr(c_col), nv.ptr(scratch), nv.ptr(flag), nv.stream())
     if not trusted and total and int(flag[0].item()):    # one check per index tensor, not per lookup (ids known in range: no read-back)
         raise IndexError("embedding index out of range")
     plan = dict(idx32=idx32, row_ptr=row_ptr, ones=ones, col_ptr=col_ptr, c_row=c_row, c_col=c_col, entries=total, rows=rows,

@@ -605,6 +605,42 @@ def test_broadcast_add_table_pack_and_accumulating_bag(E):
     assert torch.equal(acc, want)
 
 
+@pytest.mark.parametrize("n,dims", [(6500, (119, 4, 12, 12, 10, 6, 6, 2, 2)), (20181, (5, 6, 2)), (1, (3,)), (0, (7, 2)),
+                                    (333, (100,)), (5000, (300, 70000))])
+def test_embed_plan_arrays(E, n, dims):
+    """esc_embed_plan (ops.embed_plan): every array of the plan against a numpy restatement — flat keys, row pointers,
+    stable grouping by table row (CSC) — bit-exact; an id outside its table raises unless the caller vouched for the range"""
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator().manual_seed(n + len(dims))
+    k = len(dims)
+    index = torch.stack([torch.randint(0, d, (n,), generator=g0) for d in dims], 1).to(dev) if n else torch.zeros(0, k, dtype=torch.int64, device=dev)
+    plan = E.ops.embed_plan(index, dims)
+    offs = np.concatenate([[0], np.cumsum(dims)[:-1]])
+    flat = (index.cpu().numpy() + offs[None, :]).reshape(-1)
+    rows = int(sum(dims))
+    order = np.argsort(flat, kind="stable")
+    assert plan["entries"] == n * k and plan["rows"] == rows
+    assert np.array_equal(plan["idx32"].cpu().numpy(), flat.astype(np.int32))
+    assert np.array_equal(plan["row_ptr"].cpu().numpy(), np.arange(0, n * k + 1, k, dtype=np.int32))
+    assert np.array_equal(plan["ones"].cpu().numpy(), np.ones(n * k, dtype=np.int32))
+    want_ptr = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=rows))]).astype(np.int32)
+    assert np.array_equal(plan["col_ptr"].cpu().numpy(), want_ptr)
+    assert np.array_equal(plan["c_row"].cpu().numpy(), (order // k).astype(np.int32))
+    assert np.array_equal(plan["c_col"].cpu().numpy(), flat[order].astype(np.int32))
+    assert E.ops.embed_plan(index, dims) is plan                     # cached on the index tensor
+    if n > 1:
+        bad = index.clone()
+        bad[n // 2, k - 1] = dims[-1]
+        with pytest.raises(IndexError):
+            E.ops.embed_plan(bad, dims)
+        neg = index.clone()
+        neg[0, 0] = -1
+        with pytest.raises(IndexError):
+            E.ops.embed_plan(neg, dims)
+    with pytest.raises(ValueError):
+        E.ops.embed_plan(torch.zeros(4, k + 1, dtype=torch.int64, device=dev), dims)
+
+
 def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(E):
     """esc_gine_aggregate_fwd_affine / _bwd_affine (the layer input given as pre-BatchNorm rows + (scale, shift)) against
     esc_affine_act followed by the plain aggregate kernels: forward BIT-identical (same fmaf + max, same summation order),
