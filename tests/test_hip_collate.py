@@ -51,6 +51,9 @@ def test_subset_permutation_and_repeats(E):
         ref = E.BatchPlan.from_tensors(b.edge_index, b.x.size(0), b.pos_enc, b.pos_index, b.pos_batch)
         for f in E.BatchPlan.FIELDS:
             assert torch.equal(getattr(plan, f), getattr(ref, f)), (ids, f)
+        # the per-graph node pointers the fill kernel leaves for the readout pooling
+        assert plan.graph_ptr.dtype == torch.int32 and plan.num_graphs == len(ids)
+        assert plan.graph_ptr.cpu().tolist() == [0] + np.cumsum([datas[i].x.size(0) for i in ids]).tolist()
     with pytest.raises(IndexError):
         store.collate([0, 9])
     with pytest.raises(ValueError):
