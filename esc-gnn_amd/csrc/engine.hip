@@ -285,6 +285,7 @@ static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's
 // backward, esc_gine_aggregate_*_affine) and the readout GEMM (prologue over all (L+1)*H columns).  One elementwise launch
 // less per layer on the dependent node chain.  ESC_FUSE_NODE_ACT=0 / esc_engine_set_gemm_stats bit 4 switch it off.
 static int g_ogb_prologue = getenv("ESC_OGB_PROLOGUE") ? atoi(getenv("ESC_OGB_PROLOGUE")) : 1;        // OGB node MLP: BN+ReLU of the hidden layer in lin1's GEMM prologue
+static int g_ogb_split_tail = getenv("ESC_OGB_SPLIT_TAIL") ? atoi(getenv("ESC_OGB_SPLIT_TAIL")) : 0;    // OGB engine: weight gradients of the tail's two edge-row Linears on the node stream
 static int g_fuse_drop_bwd = getenv("ESC_FUSE_DROP_BWD") ? atoi(getenv("ESC_FUSE_DROP_BWD")) : 1;     // dropout backward inside the BatchNorm backward (OGB engine)
 static int g_fuse_node_act = getenv("ESC_FUSE_NODE_ACT") ? atoi(getenv("ESC_FUSE_NODE_ACT")) : 1;
 static int g_fold = getenv("ESC_BN_FOLD") ? atoi(getenv("ESC_BN_FOLD")) : 0;     // 1: both BatchNorms of an MLP merged by their consumers; 2: only the last one (by the affine pass)
@@ -1116,7 +1117,21 @@ static int backward_ogb(const OgbCtx& z) {
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));
     ESC_TRY(esc_bag_bwd_table(w.d_e, H, H, b->bonds.col_ptr, b->bonds.c_row, b->bonds.ones, b->bonds.c_col, b->bonds.n_entries,
                               m->bond_rows, y.dTcat + q.bond_row0 * H, y.emb_scratch, ce.s));
-    ESC_TRY(linear_backward(ce, w.d_e, H, y.Zemb, H, nullptr, nullptr, q.pos, E, y.dZemb, H, last ? 0 : 1));
+    if (l == 0 && es.ok && c.jobs && g_ogb_split_tail) {
+      // the LAST edge-term backward starts the tail of the step: only its input gradient (which completes d(z_emb)) stays on
+      // the edge stream; the weight gradient runs on the node stream, which has little left to do (d_e is its own product)
+      {
+        const LdsFloorGuard cap(true);
+        ESC_TRY(esc_linear_bwd_input(w.d_e, H, q.pos.w, H, E, H, H, y.dZemb, H, last ? 0 : 1, es.stream));
+      }
+      float* slabs = *c.slab_cursor;
+      *c.slab_cursor += (esc_linear_bwd_weight_scratch(E, H, H) + 63) & ~63LL;
+      c.jobs->emplace_back();
+      ESC_TRY(esc_linear_bwd_both_deferred(w.d_e, H, y.Zemb, H, nullptr, nullptr, q.pos.w, H, E, H, H, nullptr, 0, 0, q.pos.dw, H, q.pos.db,
+                                           slabs, &c.jobs->back(), c.s));
+    } else {
+      ESC_TRY(linear_backward(ce, w.d_e, H, y.Zemb, H, nullptr, nullptr, q.pos, E, y.dZemb, H, last ? 0 : 1));
+    }
     // d hin_l is complete: d h_l = d hin_l, d vn_l += add_pool(d hin_l)
     ESC_TRY(esc_segment_pool_fwd(dHin, H, b->graph_ptr, G, H, 0, y.poolG, H, c.s));
     ESC_TRY(esc_dropout_bwd(y.poolG, H, G, H, 0.f, nullptr, last ? nullptr : dvn_cur, H, dvn_cur, H, c.s));
@@ -1130,7 +1145,20 @@ static int backward_ogb(const OgbCtx& z) {
   ESC_TRY(esc_embed_bwd(dvn_next, H, b->zero_idx, G, 1, H, m->vn_dw, c.s));
   // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order)
   ESC_TRY(bn_backward_drop(ce, y.Yzd, H, y.dZemb, H, E, y.zb1, m->zbn1, y.mask_z1, p, 1, y.dYz, H, ce.y.bn_scratch));
-  ESC_TRY(linear_backward(ce, y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dA0, H, 0));
+  if (es.ok && c.jobs && g_ogb_split_tail) {      // same split for z_embedding's Linear: dX continues the tail, dW on the node stream
+    ESC_TRY(chain(es.tail_dz, es.stream, (hipStream_t)c.s));           // d(Yz) is complete here in edge-stream order
+    {
+      const LdsFloorGuard cap(true);
+      ESC_TRY(esc_linear_bwd_input(y.dYz, H, m->zlin.w, H, E, H, H, y.dA0, H, 0, es.stream));
+    }
+    float* slabs = *c.slab_cursor;
+    *c.slab_cursor += (esc_linear_bwd_weight_scratch(E, H, H) + 63) & ~63LL;
+    c.jobs->emplace_back();
+    ESC_TRY(esc_linear_bwd_both_deferred(y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin.w, H, E, H, H, nullptr, 0, 0, m->zlin.dw, H, m->zlin.db,
+                                         slabs, &c.jobs->back(), c.s));
+  } else {
+    ESC_TRY(linear_backward(ce, y.dYz, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dA0, H, 0));
+  }
   ESC_TRY(bn_backward_drop(ce, y.Zd, H, y.dA0, H, E, y.zb0, m->zbn0, y.mask_z0, p, 1, y.dA0, H, ce.y.bn_scratch));
   ESC_TRY(esc_bag_bwd_table_rows(y.dA0, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
                                  m->dz_table, y.bag_scratch, ce.s));
