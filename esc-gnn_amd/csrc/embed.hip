@@ -75,6 +75,69 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   }
 }
 
+// float4 form for narrow tables (C % 4 == 0, C <= 256: the 32-wide node / edge type embeddings of ZINC): C/4 lanes cover a
+// gradient row, so 256 / (C/4) row groups (32 at C = 32, against 8 above) walk the match list side by side with four rows in
+// flight each — a type with 1 600 matches is 13 dependent batches per thread instead of 50.  Same fixed summation tree
+// for a given (M, C): partial of row group rg = rows rg, rg+RG, ... in ascending order, groups combined in ascending rg.
+__global__ __launch_bounds__(256) void embed_bwd_kernel_v4(const float* __restrict__ g, int64_t ld, const int64_t* __restrict__ idx,
+                                                           int64_t M, int C, float* __restrict__ dtable) {
+  __shared__ int list[4][EMB_SLICE / 4];
+  __shared__ int cnt[4];
+  __shared__ float4 part[256];
+  const int r = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int CW = C >> 2;                                   // lanes per row (1 .. 64)
+  const int RG = 256 / CW;                                 // row groups; threads beyond RG * CW idle (C/4 not a divisor of 256)
+  const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
+  const bool active = rg < RG;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t s0 = 0; s0 < M; s0 += EMB_SLICE) {
+    const int64_t q0 = s0 + (int64_t)wave * (EMB_SLICE / 4);
+    int n = 0;
+    for (int t = 0; t < EMB_SLICE / 4; t += 64) {
+      const int64_t i = q0 + t + lane;
+      const bool hit = i < M && idx[i] == r;
+      const unsigned long long m = __ballot(hit);
+      if (hit) list[wave][n + __popcll(m & ((1ull << lane) - 1ull))] = (int)(i - s0);
+      n += __popcll(m);
+      if (q0 + t + 64 >= M) break;                        // wave-uniform
+    }
+    if (lane == 0) cnt[wave] = n;
+    __syncthreads();
+    if (active) {
+      for (int w = 0; w < 4; ++w) {                        // wave-major = ascending position
+        const int nw = cnt[w];
+        int j = rg;
+        for (; j + 3 * RG < nw; j += 4 * RG) {
+          const float4 a0 = *reinterpret_cast<const float4*>(g + (s0 + list[w][j]) * ld + 4 * c);
+          const float4 a1 = *reinterpret_cast<const float4*>(g + (s0 + list[w][j + RG]) * ld + 4 * c);
+          const float4 a2 = *reinterpret_cast<const float4*>(g + (s0 + list[w][j + 2 * RG]) * ld + 4 * c);
+          const float4 a3 = *reinterpret_cast<const float4*>(g + (s0 + list[w][j + 3 * RG]) * ld + 4 * c);
+          acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+          acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+          acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+          acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w;
+        }
+        for (; j < nw; j += RG) {
+          const float4 a = *reinterpret_cast<const float4*>(g + (s0 + list[w][j]) * ld + 4 * c);
+          acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (rg == 0) {
+    float4 sum = part[c];
+    for (int k = 1; k < RG; ++k) {
+      const float4 v = part[k * CW + c];
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dtable + (int64_t)r * C + 4 * c) = sum;
+  }
+}
+
 // out[i,:] = x[i,:] + rows[graph(i),:] — the virtual-node broadcast h + vn[batch] (ogb_mol_gnn.py:739); one thread per
 // float4 of the output, the graph of a row found by bisection of seg_ptr (G+1 ints, L1/L2 resident)
 __global__ __launch_bounds__(256) void segment_broadcast_add_kernel(const float* __restrict__ x, int64_t ld_x,
@@ -213,6 +276,11 @@ int esc_embed_bwd(const float* g, int64_t ld_g, const int64_t* idx, int64_t M, i
   ESC_REQUIRE(rows > 0 && rows <= 4096 && C > 0 && ld_g >= C && M >= 0, "esc_embed_bwd: table of %ld rows x %ld is not a small one", (long)rows, (long)C);
   if (rows == 1) {
     esc::launch(ESC_K_BAG_BWD, embed_bwd_one_row_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, g, ld_g, M, C, dtable);
+    ESC_CHECK_LAUNCH("esc_embed_bwd");
+    return ESC_OK;
+  }
+  if (C % 4 == 0 && C <= 256 && ld_g % 4 == 0 && aligned16(g) && aligned16(dtable)) {
+    esc::launch(ESC_K_BAG_BWD, embed_bwd_kernel_v4, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, g, ld_g, idx, M, (int)C, dtable);
     ESC_CHECK_LAUNCH("esc_embed_bwd");
     return ESC_OK;
   }

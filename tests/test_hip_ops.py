@@ -433,7 +433,7 @@ def test_reduce_sum_jobs(E):
 
 
 # ---- building blocks of the ZINC / OGB step engines (csrc/embed.hip, bag.hip) -------------------------------------------
-@pytest.mark.parametrize("M,rows,C", [(6400, 100, 32), (2400, 28, 32), (20000, 5, 300), (256, 1, 300), (3, 7, 8), (17000, 3, 64)])
+@pytest.mark.parametrize("M,rows,C", [(6400, 100, 32), (2400, 28, 32), (20000, 5, 300), (256, 1, 300), (3, 7, 8), (17000, 3, 64), (5000, 9, 12), (9000, 4, 256)])
 def test_small_table_embedding_kernels(E, M, rows, C):
     """esc_embed_fwd / esc_embed_bwd (type-embedding lookups of zinc_models.py:581,591) against index_select / index_add_
     in fp64; the gradient is bitwise reproducible; an out-of-range index yields a zero row and raises the flag."""
