@@ -286,6 +286,7 @@ static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's
 // less per layer on the dependent node chain.  ESC_FUSE_NODE_ACT=0 / esc_engine_set_gemm_stats bit 4 switch it off.
 static int g_ogb_prologue = getenv("ESC_OGB_PROLOGUE") ? atoi(getenv("ESC_OGB_PROLOGUE")) : 1;        // OGB node MLP: BN+ReLU of the hidden layer in lin1's GEMM prologue
 static int g_ogb_split_tail = getenv("ESC_OGB_SPLIT_TAIL") ? atoi(getenv("ESC_OGB_SPLIT_TAIL")) : 0;    // OGB engine: weight gradients of the tail's two edge-row Linears on the node stream
+static int g_ogb_bonds_on_node = getenv("ESC_OGB_BONDS_ON_NODE") ? atoi(getenv("ESC_OGB_BONDS_ON_NODE")) : 1;   // 4.34 -> 4.31 ms/step
 static int g_fuse_drop_bwd = getenv("ESC_FUSE_DROP_BWD") ? atoi(getenv("ESC_FUSE_DROP_BWD")) : 1;     // dropout backward inside the BatchNorm backward (OGB engine)
 static int g_fuse_node_act = getenv("ESC_FUSE_NODE_ACT") ? atoi(getenv("ESC_FUSE_NODE_ACT")) : 1;
 static int g_fold = getenv("ESC_BN_FOLD") ? atoi(getenv("ESC_BN_FOLD")) : 0;     // 1: both BatchNorms of an MLP merged by their consumers; 2: only the last one (by the affine pass)
@@ -1115,8 +1116,13 @@ static int backward_ogb(const OgbCtx& z) {
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, q.deps});
     // edge term: bond tables and edge_encoder_pos — edge stream
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));
+    // bond tables: on the edge stream — except for the LAST layer processed (l == 0), whose edge-term backward opens the tail of
+    // the step: there the table gradient runs on the node stream (d_e is its own product; it has the atom tables' scratch to
+    // itself until the encoders below) and the edge stream goes straight to the Linear that completes d(z_emb)
+    const bool bonds_on_node = l == 0 && es.ok && g_ogb_bonds_on_node;
     ESC_TRY(esc_bag_bwd_table(w.d_e, H, H, b->bonds.col_ptr, b->bonds.c_row, b->bonds.ones, b->bonds.c_col, b->bonds.n_entries,
-                              m->bond_rows, y.dTcat + q.bond_row0 * H, y.emb_scratch, ce.s));
+                              m->bond_rows, y.dTcat + q.bond_row0 * H, bonds_on_node ? y.emb_scratch_n : y.emb_scratch,
+                              bonds_on_node ? c.s : ce.s));
     if (l == 0 && es.ok && c.jobs && g_ogb_split_tail) {
       // the LAST edge-term backward starts the tail of the step: only its input gradient (which completes d(z_emb)) stays on
       // the edge stream; the weight gradient runs on the node stream, which has little left to do (d_e is its own product)
