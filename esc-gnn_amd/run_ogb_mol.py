@@ -59,8 +59,8 @@ _FLAGS = [  # same names, types and defaults as the reference CLI (its `type=boo
     # additions (not in the reference): size of the synthetic stand-in dataset
     ("--synthetic_graphs", dict(type=int, default=4000, help="molecules; split 80/10/10 by index")),
     ("--prefetch", dict(action="store_true", default=False,
-                        help="collate the next batch on a side stream (harness.prefetched); measured neutral-to-slower on "
-                             "MI355X at bs=256, see DESIGN.md 4")),
+                        help="collate the next batch on a side stream (harness.prefetched): 4.21 vs 4.31 ms/step on MI355X at "
+                             "config 5 (bs=256, emb 300), see DESIGN.md 4")),
 ]
 
 TASKS = {"ogbg-molhiv": (1, 0.0), "ogbg-molpcba": (128, 0.6)}     # (num_tasks, NaN-label ratio of the stand-in)

@@ -54,8 +54,8 @@ _FLAGS = [  # same names, types and defaults as the reference CLI
     # additions (not in the reference): size of the synthetic stand-in for the absent ZINC.pkl
     ("--synthetic_graphs", dict(type=int, default=12000, help="train+val+test molecules (10:1:1 like ZINC-12k)")),
     ("--prefetch", dict(action="store_true", default=False,
-                        help="collate the next batch on a side stream (harness.prefetched); measured neutral-to-slower on "
-                             "MI355X at bs=128, see DESIGN.md 4")),
+                        help="collate the next batch on a side stream (harness.prefetched); slower on MI355X at config 4 "
+                             "(1.20 vs 1.11 ms/step: the step is a chain of small launches), see DESIGN.md 4")),
     ("--sync_bn", dict(action="store_true", default=False,
                        help="data parallel only: BatchNorm statistics over all ranks (single-device-equivalent numerics)")),
 ]
