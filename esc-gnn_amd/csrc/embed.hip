@@ -168,8 +168,17 @@ __global__ __launch_bounds__(256) void embed_bwd_one_row_kernel(const float* __r
   const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int q = threadIdx.x >> 6;
   float acc = 0.f;
-  if (c < C)
-    for (int64_t i = q; i < M; i += 4) acc += g[i * ld + c];
+  if (c < C) {
+    int64_t i = q;
+    for (; i + 28 < M; i += 32) {                 // eight rows in flight (loads first, then the adds in row order)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = g[(i + 4 * u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; i < M; i += 4) acc += g[i * ld + c];
+  }
   part[threadIdx.x] = acc;
   __syncthreads();
   if (q == 0 && c < C) dtable[c] = ((part[threadIdx.x] + part[threadIdx.x + 64]) + part[threadIdx.x + 128]) + part[threadIdx.x + 192];
