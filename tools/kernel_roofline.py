@@ -53,6 +53,21 @@ def timed_rotating(kind, fns, n=60):
     return ms / n * 1e3, launches / n
 
 
+def timed_wall(fn, n=100):
+    """stream time per call of n back-to-back calls (torch events around the whole run: launch gaps included) — the only
+    clock that treats a library GEMM and ours alike"""
+    for _ in range(10):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
 def main():
     graphs = build_count_dataset(0, 256, h=3)
     store = E.DeviceGraphStore(graphs, dev)
@@ -142,6 +157,16 @@ def main():
         slabs = torch.empty(int(nv.lib().esc_linear_bwd_weight_scratch(rows_, n_out, k_in)), device=dev)
         us, k = timed("linear", lambda: nv.call("esc_linear_bwd_both", nv.ptr(c), n_out, nv.ptr(a), k_in, None, None, nv.ptr(w2), k_in, rows_, n_out, k_in, nv.ptr(da), k_in, 0, nv.ptr(dw), k_in, nv.ptr(dbb), nv.ptr(slabs), s))
         add("Linear backward dX+dW (+reduce), " + name, us, k, flops=4.0 * rows_ * n_out * k_in)
+    # the vendor library on the same shapes (torch.addmm -> rocBLAS / hipBLASLt, fp32, no TF32 on gfx950), same clock for both
+    torch.backends.cuda.matmul.allow_tf32 = False
+    for name, rows_, n_out, k_in in (("edge rows 15200x256x256", Ee, H, H), ("node rows 2400x256x256", N, H, H),
+                                     ("edge rows 20000x300x300", 20000, 300, 300), ("node rows 6500x600x300", 6500, 600, 300)):
+        a = torch.randn(rows_, k_in, device=dev); c = torch.empty(rows_, n_out, device=dev)
+        w2 = torch.randn(n_out, k_in, device=dev); b2 = torch.randn(n_out, device=dev)
+        us_lib = timed_wall(lambda: torch.addmm(b2, a, w2.t(), out=c))
+        us_own = timed_wall(lambda: nv.call("esc_linear_fwd", nv.ptr(a), k_in, nv.ptr(w2), k_in, nv.ptr(b2), None, None, rows_, n_out, k_in, nv.ptr(c), n_out, None, s))
+        add("Linear forward wall/call, " + name + ": esc_linear_fwd", us_own, 1, flops=2.0 * rows_ * n_out * k_in)
+        add("Linear forward wall/call, " + name + ": torch.addmm (vendor library)", us_lib, 1, flops=2.0 * rows_ * n_out * k_in)
     print("MI355X, BASELINE config 1 shapes: N=%d E=%d Z=%d H=%d; peaks: HBM %.0f GB/s, fp32 MFMA %.1f TFLOP/s" % (N, Ee, Z, H, HBM, MFMA))
     head = ("kernel (back to back)", "us/call", "launches", "algorithmic", "achieved", "of peak")
     wid = [max(len(r[i]) for r in rows + [head]) for i in range(6)]
