@@ -185,7 +185,10 @@ int64_t esc_plan_csr_scratch(int64_t n, int64_t n_keys) {
 int esc_plan_csr(const int64_t* key, int64_t n, int64_t n_keys, int32_t* ptr, int32_t* perm, int32_t* scratch,
                  int32_t* bad_flag, void* stream) {
   ESC_REQUIRE(ptr && scratch && bad_flag && (n == 0 || key), "esc_plan_csr: null pointer");
-  ESC_REQUIRE(n >= 0 && n < (1LL << 31) && n_keys > 0 && n_keys < (1LL << 24), "esc_plan_csr: bad sizes n=%ld n_keys=%ld", (long)n, (long)n_keys);
+  // the radix passes sort on 24 key bits; segment pointers alone (perm == NULL: keys already grouped, e.g. row_ptr keyed on E) only
+  // need the int32 counters to hold n_keys + 1 entries
+  ESC_REQUIRE(n >= 0 && n < (1LL << 31) && n_keys > 0 && n_keys < (perm ? (1LL << 24) : (1LL << 31) - 64),
+              "esc_plan_csr: bad sizes n=%ld n_keys=%ld", (long)n, (long)n_keys);
   hipStream_t s = (hipStream_t)stream;
   const int nblk = (int)cdiv(n > 0 ? n : 1, PLAN_CHUNK);
   int* idx_a = scratch;

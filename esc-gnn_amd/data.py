@@ -112,11 +112,30 @@ class Data(object):
     def to(self, device, non_blocking=False):
         d = object.__getattribute__(self, "__dict__")
         plan = d.get("_esc_plan")
+        still_valid = False
+        if plan is not None:                                 # judged BEFORE the move: a plan that is already stale (edge dropout,
+            from .plan import plan_key                       # an edited pos_* tensor) must not be stamped valid by the re-key below
+            from .plan import _sig
+            still_valid = getattr(plan, "_key", None) == plan_key(self, plan.n_cols)
+            batch_valid = plan.graph_ptr is not None and plan._batch_sig == _sig(self._store.get("batch"))
+        ranges = d.get("_esc_int_ranges")
+        trusted = ()
+        if ranges is not None:                               # which integer features are still the tensors the store signed
+            trusted = [k for k, (addr, ver) in ranges[1].items() if torch.is_tensor(self._store.get(k)) and
+                       (self._store[k].data_ptr(), self._store[k]._version) == (addr, ver)]
         out = self.apply(lambda t: t.to(device, non_blocking=non_blocking))
-        if plan is not None:                                 # the plan follows its tensors; re-key it on their new identity
-            from .plan import plan_key
-            plan.to(device)
-            plan._key = plan_key(self, plan.n_cols)
+        if plan is not None:
+            if still_valid:                                  # the plan follows its tensors; re-key it on their new identity
+                plan.to(device)
+                plan._key = plan_key(self, plan.n_cols)
+                if batch_valid:
+                    plan._batch_sig = _sig(self._store.get("batch"))
+                else:
+                    plan.graph_ptr, plan.num_graphs, plan._batch_sig = None, None, None
+            else:
+                d.pop("_esc_plan", None)                     # plan_of() rebuilds it from the tensors as they are now
+        if ranges is not None:                               # (address, version) signatures of the integer features: follow the move
+            d["_esc_int_ranges"] = (ranges[0], {k: (self._store[k].data_ptr(), self._store[k]._version) for k in trusted})
         return out
 
     def contiguous(self):

@@ -195,6 +195,17 @@ class _AddressGuard(object):
         if self._sentinels() != self._guard_sig:
             self.refresh()
 
+    def _mark_bucket_written(self):
+        """train_step OVERWRITES the .grad storage through raw addresses, which torch's version counter does not see: a
+        FlatBucket that still believes it is as zero_grad() left it would let a later `model(batch).backward()` write
+        straight into it (overwriting this step's gradients instead of accumulating onto them)."""
+        from .parallel import _BUCKETS
+        g0 = self._guard_params[0].grad
+        base = getattr(g0, "_base", None) if g0 is not None else None
+        bucket = _BUCKETS.get(base.data_ptr()) if base is not None else None
+        if bucket is not None:
+            bucket._clean_version = None
+
 
 class StepEngine(_AddressGuard):
     def __init__(self, model):
@@ -262,6 +273,7 @@ class StepEngine(_AddressGuard):
         pred = torch.empty(b.N, dtype=torch.float32, device=dev) if return_pred else None
         nv.call(_entry, ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(),
                 int(loss_denom or 0), loss.data_ptr(), nv.ptr(pred), nv.stream())
+        self._mark_bucket_written()
         self._open = (keep, ws) if _entry.endswith("_begin") else None     # operands stay alive until end_step
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)
@@ -340,7 +352,12 @@ class _NodeCache(object):
         g0 = self.params[0].grad
         base = getattr(g0, "_base", None) if g0 is not None else None
         bucket = _BUCKETS.get(base.data_ptr()) if base is not None else None
-        return bucket.direct_grad_addresses(self.params) if bucket is not None else None
+        if bucket is None:
+            return None
+        for p in self.params:          # tensor hooks / post-accumulate hooks (DDP-style wrappers) only fire on returned gradients
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+                return None
+        return bucket.direct_grad_addresses(self.params)
 
 
 def _node_cache(model):
@@ -375,6 +392,9 @@ class _EngineNode(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
         cache = ctx.cache
+        if ctx.ws is None:
+            raise RuntimeError("esc_gnn_amd: this engine node's workspace was released by its first backward; a second "
+                               "backward through the same forward (retain_graph=True) needs the per-op path")
         g = dpred.reshape(-1)
         g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
         direct = cache.direct_bucket()
@@ -477,6 +497,21 @@ def _zinc_batch(model, data, need_y):
     et = et if (et.dtype == torch.int64 and et.is_contiguous()) else et.to(torch.int64).contiguous()
     if nt.numel() != b.N or et.numel() != b.E:
         raise ValueError("ZINC engine: expected one type id per node and per edge")
+    # the lookup kernels turn an out-of-range id into a zero row (in bounds, but silent): ids are trusted only when the
+    # device store signed these very tensors with a dataset-wide range inside the tables; anything else is checked once
+    # per tensor version (one read-back), like torch.nn.Embedding's IndexError on the per-op path
+    rng, sig = data.__dict__.get("_esc_int_ranges") or ({}, {})
+    for key, src, ids, rows in (("x", data.x, nt, model.node_type_embedding.num_embeddings),
+                                ("edge_attr", data.edge_attr, et, model.edge_type_embedding.num_embeddings)):
+        r = rng.get(key) if sig.get(key) == (src.data_ptr(), src._version) else None
+        if r is not None and min(r[0]) >= 0 and max(r[1]) < rows:
+            continue
+        seen = getattr(src, "_esc_zinc_checked", None)
+        if seen == (src._version, rows):
+            continue
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= rows):
+            raise IndexError("ZINC engine: %s holds a type id outside the %d-row embedding table" % (key, rows))
+        src._esc_zinc_checked = (src._version, rows)
     b.node_type, b.edge_type, b.graph_ptr = nt.data_ptr(), et.data_ptr(), gptr.data_ptr()
     y = None
     if need_y:
@@ -530,6 +565,7 @@ class ZincStepEngine(_AddressGuard):
         pred = torch.empty(b.G, dtype=torch.float32, device=dev) if return_pred else None
         nv.call("esc_zinc_train_step", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), int(loss_denom or 0),
                 loss.data_ptr(), nv.ptr(pred), nv.stream())
+        self._mark_bucket_written()
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)
         return (loss.view(()), pred.view(-1, 1)) if return_pred else loss.view(())
@@ -572,6 +608,9 @@ class _ZincEngineNode(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
         cache = ctx.cache
+        if ctx.ws is None:
+            raise RuntimeError("esc_gnn_amd: this engine node's workspace was released by its first backward; a second "
+                               "backward through the same forward (retain_graph=True) needs the per-op path")
         g = dpred.reshape(-1)
         g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
         direct = cache.direct_bucket()
@@ -812,6 +851,7 @@ class OgbStepEngine(_AddressGuard):
         pred = torch.empty((b.G, self.model.num_tasks), dtype=torch.float32, device=dev) if return_pred else None
         nv.call("esc_ogb_train_step", ctypes.byref(self._desc), ctypes.byref(b), ws.data_ptr(), int(loss_denom or 0),
                 loss.data_ptr(), nv.ptr(pred), nv.stream())
+        self._mark_bucket_written()
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)
         return (loss.view(()), pred) if return_pred else loss.view(())
@@ -854,6 +894,9 @@ class _OgbEngineNode(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
         cache = ctx.cache
+        if ctx.ws is None:
+            raise RuntimeError("esc_gnn_amd: this engine node's workspace was released by its first backward; a second "
+                               "backward through the same forward (retain_graph=True) needs the per-op path")
         g = dpred.reshape(-1)
         g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
         direct = cache.direct_bucket()

@@ -54,6 +54,7 @@ class BatchPlan(object):
         self.nnz = kw["nnz"]
         self.n_cols = kw.get("n_cols", 1800)
         self.graph_ptr, self.num_graphs = None, None      # node range of every graph: set by the device collate / graph_ptr_of
+        self._batch_sig = None                            # ... valid for exactly this `batch` vector (address, shape, version)
 
     def to(self, device):
         for f in self.FIELDS:
@@ -125,10 +126,11 @@ def plan_of(data, n_cols=1800):
 def graph_ptr_of(data, plan):
     """int32 [G+1] node range of every graph of a batch (its `batch` vector is non-decreasing) and G; from the device
     collate when the batch came from there, else one esc_plan_csr call, cached on the plan."""
-    if plan.graph_ptr is None:
+    if plan.graph_ptr is None or plan._batch_sig != _sig(data.batch):     # a re-assigned / edited `batch` moves the graph bounds
         batch = data.batch
         G = int(batch[-1].item()) + 1 if batch.numel() else 0
         if batch.numel() > 1 and not bool((batch[1:] >= batch[:-1]).all()):
             raise ValueError("the batch vector must be non-decreasing")
         plan.graph_ptr, plan.num_graphs = _csr(batch, max(G, 1), want_perm=False)[0], G
+        plan._batch_sig = _sig(batch)
     return plan.graph_ptr, plan.num_graphs

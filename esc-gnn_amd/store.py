@@ -13,7 +13,7 @@ import torch
 
 from . import _native as nv
 from .batch import Batch
-from .plan import BatchPlan, plan_key
+from .plan import BatchPlan, plan_key, _sig
 
 N_COLS = 1800
 
@@ -256,6 +256,7 @@ class DeviceGraphStore(object):
                          n_cols=N_COLS)
         plan._keepalive = (slab, offs_d, ids_d)
         plan.graph_ptr, plan.num_graphs = graph_ptr, B       # node range of every graph (readout pooling)
+        plan._batch_sig = _sig(batch)
         object.__setattr__(out, "_num_graphs", B)
         batch._esc_seg = {(batch._version, None): plan.graph_ptr, (batch._version, B): plan.graph_ptr}   # pooling ops: no rebuild, no read-back
         # the dataset-wide value range of the integer features, valid for exactly these tensors in their current version

@@ -12,7 +12,7 @@ def _to_data(g):
     return E.Data(**{k: torch.tensor(v) for k, v in g.items()})
 
 
-@pytest.mark.parametrize("tag", ["count3", "mixed4"])
+@pytest.mark.parametrize("tag", ["count3", "mixed4", "zinc3", "molhiv4"])
 def test_from_data_list_matches_reference(tag):
     graphs, ref, num_graphs = load_collate(tag)
     b = E.Batch.from_data_list([_to_data(g) for g in graphs])
@@ -53,3 +53,31 @@ def test_dataloader_batches():
     datas = [_to_data(g) for g in graphs]
     out = list(E.DataLoader(datas, batch_size=3))
     assert [b.num_graphs for b in out] == [3, 1]
+
+
+def test_to_does_not_revalidate_a_stale_plan():
+    """Data.to() used to re-key the cached plan unconditionally: after edge dropout (a new edge_index) the stale plan was
+    stamped valid and model(data) -- which calls data.to(device) before plan_of -- aggregated over the old E.  The
+    validity is now judged BEFORE the move (reference call order: run_graphcount.py:134-135 `data.to`, then the layers)."""
+    from esc_gnn_amd.plan import BatchPlan, plan_key, _sig
+    graphs, _, _ = load_collate("count3")
+    b = E.Batch.from_data_list([_to_data(g) for g in graphs])
+    plan = BatchPlan(num_nodes=b.x.size(0), num_edges=b.edge_index.size(1), nnz=b.pos_enc.numel())
+    plan._key = plan_key(b, plan.n_cols)
+    plan.graph_ptr, plan.num_graphs, plan._batch_sig = torch.zeros(4, dtype=torch.int32), 3, _sig(b.batch)
+    object.__setattr__(b, "_esc_plan", plan)
+    b.to("cpu")                                           # unchanged tensors: the plan stays, re-keyed
+    assert b.__dict__["_esc_plan"] is plan and plan._key == plan_key(b, plan.n_cols) and plan.graph_ptr is not None
+    b.batch = b.batch.clone()                             # a re-assigned batch vector: graph bounds must be rebuilt
+    b.to("cpu")
+    assert b.__dict__["_esc_plan"] is plan and plan.graph_ptr is None and plan._batch_sig is None
+    b.edge_index = b.edge_index[:, ::2].contiguous()      # edge dropout: a new edge_index
+    assert plan._key != plan_key(b, plan.n_cols)
+    b.to("cpu")
+    assert "_esc_plan" not in b.__dict__                  # dropped, not stamped valid
+    # in-place edits move the version counter and are caught the same way
+    plan._key = plan_key(b, plan.n_cols)
+    object.__setattr__(b, "_esc_plan", plan)
+    b.pos_enc.add_(1)
+    b.to("cpu")
+    assert "_esc_plan" not in b.__dict__

@@ -24,20 +24,31 @@ def _store(E, tag):
     return E.DeviceGraphStore(datas, "cuda:0"), datas, ref, ng
 
 
-@pytest.mark.parametrize("tag", ["count3", "mixed4"])
+@pytest.mark.parametrize("tag", ["count3", "mixed4", "zinc3", "molhiv4"])
 def test_device_collate_matches_reference(E, tag):
+    """every tensor of the reference's batch.py output (batch.py:25-149), bit for bit and dtype for dtype: fp32 x of the
+    counting data, int64 categorical x (ZINC 1-D, molhiv [n, 9]) and the gathered edge_attr rows (1-D / [E, 3])"""
     store, datas, ref, ng = _store(E, tag)
     b = store.collate(list(range(len(datas))))
     assert sorted(b.keys) == sorted(ref.keys())
     for k, v in ref.items():
         got = b[k].cpu()
         assert got.dtype == torch.tensor(v).dtype, k
+        assert tuple(got.shape) == tuple(v.shape), k
         assert np.array_equal(got.numpy(), v), k
     assert b.num_graphs == ng
     plan = b.__dict__["_esc_plan"]
     want = E.BatchPlan.from_tensors(b.edge_index, b.x.size(0), b.pos_enc, b.pos_index, b.pos_batch)
     for f in E.BatchPlan.FIELDS:
         assert torch.equal(getattr(plan, f), getattr(want, f)), f
+    # graph pointers of the fill kernel = node ranges of the reference's `batch` vector
+    gp = plan.graph_ptr.cpu().numpy()
+    assert plan.graph_ptr.dtype == torch.int32 and plan.num_graphs == ng
+    assert np.array_equal(gp, np.concatenate([[0], np.cumsum(np.bincount(ref["batch"], minlength=ng))]))
+    # ... and the host collate agrees on the same goldens (same keys, same dtypes)
+    host = E.Batch.from_data_list(datas)
+    for k in ref:
+        assert torch.equal(host[k], b[k].cpu()), k
 
 
 def test_subset_permutation_and_repeats(E):
@@ -132,6 +143,46 @@ def test_plan_cache_follows_the_index_tensors(E):
     assert p3 is not p2
     src = data.edge_index[0][p3.out_edge.long()]
     assert bool((src[1:] >= src[:-1]).all())
+
+
+def test_model_forward_rebuilds_a_stale_plan(E):
+    """NestedGIN_eff.forward calls data.to(device) BEFORE plan_of (run_graphcount.py:134-135): after edge dropout the cached
+    plan must be rebuilt by that call chain, not stamped valid by Data.to() (it indexes the old E and Z: wrong sums or
+    out-of-range int32 reads)."""
+    _, b, _ = load_collate("count3")
+    torch.manual_seed(0)
+    model = E.NestedGIN_eff(None, 2, 32, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to(DEV).eval()
+    data = E.Data(**{k: torch.tensor(v) for k, v in b.items()}).to(DEV)
+    with torch.no_grad():
+        model(data)
+    p1 = data.__dict__["_esc_plan"]
+    keep = torch.arange(0, data.edge_index.size(1), 2, device=DEV)
+    sel = torch.isin(data.pos_batch, keep)
+    remap = torch.full((int(keep.max()) + 1,), -1, device=DEV, dtype=torch.long); remap[keep] = torch.arange(keep.numel(), device=DEV)
+    data.edge_index = data.edge_index[:, keep]
+    data.pos_enc, data.pos_index, data.pos_batch = data.pos_enc[sel], data.pos_index[sel], remap[data.pos_batch[sel]]
+    with torch.no_grad():
+        got = model(data)
+    p2 = data.__dict__["_esc_plan"]
+    assert p2 is not p1 and p2.num_edges == keep.numel() and p2.nnz == int(sel.sum())
+    fresh = E.Data(**{k: data[k].clone() for k in data.keys})
+    with torch.no_grad():
+        want = model(fresh)
+    assert torch.equal(got, want)
+
+
+def test_segment_pointers_beyond_the_radix_key_range(E):
+    """esc_plan_csr sorts on 24 key bits; pointer-only calls (perm == NULL: keys already grouped, e.g. row_ptr keyed on the
+    edge count) have no such limit"""
+    from esc_gnn_amd.plan import _csr
+    n_keys = (1 << 24) + 1000
+    key = torch.sort(torch.randint(0, n_keys, (5000,), generator=torch.Generator().manual_seed(1)))[0]
+    ptr, none = _csr(key.to(DEV), n_keys, want_perm=False)
+    want = torch.zeros(n_keys + 1, dtype=torch.int64)
+    want[1:] = torch.cumsum(torch.bincount(key, minlength=n_keys), 0)
+    assert none is None and torch.equal(ptr.cpu().long(), want)
+    with pytest.raises(RuntimeError):
+        _csr(key.to(DEV), n_keys, want_perm=True)
 
 
 def test_reference_data_slices_layout_round_trip(E, tmp_path):
