@@ -133,13 +133,14 @@ def main():
         stats["nnz"] += b.pos_enc.numel()
 
     nxt = {"b": None}
+    mode = {"scaling": args.scaling, "store": store}      # what step() runs: the headline mode, then (N > 1) the other one
 
     def next_ids(i):
         """weak scaling: every rank walks its own split in batches of --batch_size graphs (per-GPU work fixed).
         strong scaling: ONE global batch of --batch_size graphs per step, rank r collates its contiguous
         slice [r*B/W, (r+1)*B/W) of it (run_graphcount.py's data-parallel mode)."""
         ids = batch_ids[i % nb]
-        if args.scaling == "strong" and world > 1:
+        if mode["scaling"] == "strong" and world > 1:
             lo, hi = E.parallel.shard_slice(ids.numel(), rank, world)
             return ids[lo:hi]
         return ids
@@ -147,6 +148,7 @@ def main():
     def step(i, count=False):
         # host ids: async pinned staging, no host/device sync.  Engine path: the NEXT batch is collated between the two
         # halves of the step, i.e. on the node stream while the edge pipeline finishes its backward
+        store = mode["store"]
         b = nxt["b"] if nxt["b"] is not None else store.collate(next_ids(i))
         nxt["b"] = None
         if engine is not None:
@@ -202,6 +204,48 @@ def main():
         total_graphs, total_edges = float(tot[0]), float(tot[1])
     else:
         total_graphs, total_edges = float(stats["graphs"]), float(stats["edges"])
+
+    # ---- N > 1: the OTHER scaling mode, same K / W, barrier and max-over-ranks timing (SURVEY 8e slices ONE global batch of
+    # --batch_size graphs over the ranks = "strong"; the headline default keeps --batch_size graphs per GPU = "weak") ------
+    other = None
+    if world > 1:
+        other_mode = "strong" if args.scaling == "weak" else "weak"
+        if other_mode == "strong" and rank != 0:           # strong: every rank slices the SAME split (rank 0's)
+            g0 = build_count_dataset(0, args.graphs, h=args.h, use_rd=True, self_loop=True)
+            for g in g0:
+                g.y = (g.y.view(-1) - mean) / std
+            mode["store"] = DeviceGraphStore(g0, dev)
+        elif other_mode == "weak" and rank != 0:           # weak: every rank walks its own split
+            gr = build_count_dataset(rank * args.graphs, args.graphs, h=args.h, use_rd=True, self_loop=True)
+            for g in gr:
+                g.y = (g.y.view(-1) - mean) / std
+            mode["store"] = DeviceGraphStore(gr, dev)
+        mode["scaling"] = other_mode
+        nxt["b"] = None
+        keep = dict(stats)
+        for k in stats:
+            stats[k] = 0
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, count=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tot = torch.tensor([stats["graphs"], stats["edges"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot)
+        other = dict(scaling=other_mode, value=round(float(tot[0]) / float(t), 1), unit="graphs/s",
+                     ms_per_step=round(float(t) / args.steps * 1e3, 3),
+                     edges_aggregated_per_s=round(float(tot[1]) * args.layers / float(t), 1),
+                     global_batch=args.batch_size * (world if other_mode == "weak" else 1),
+                     graphs_per_rank_and_step=round(float(tot[0]) / args.steps / world, 1))
+        stats.update(keep)
+        mode["scaling"], mode["store"] = args.scaling, store
+        nxt["b"] = None
 
     # ---- per-family breakdown (separate instrumented steps, not part of `value`) -------------------
     breakdown = {}
@@ -330,7 +374,8 @@ def main():
                                % (args.h, args.layers, args.hidden, args.batch_size),
                    "global_batch": args.batch_size * (world if args.scaling == "weak" else 1),
                    "parallelism": "dp%d graph-sharded" % world, "step_path": args.path,
-                   "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                   "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)),
+                   "ranks": world,
                    "collective_backend": (dist.get_backend() if world > 1 else None),
                    "grad_allreduce": ("two buckets: node-pipeline gradients during the edge backward tail, edge-pipeline gradients "
                                       "+ node count after the join" if world > 1 else None),
@@ -343,6 +388,12 @@ def main():
                           "note": "graph generation (networkx) + HIP create_subgraphs_many + host copies"},
         "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in breakdown.items()},
     }
+    if world > 1:                     # both scaling modes in one line: `value` is the --scaling one, the other rides along
+        this = dict(scaling=args.scaling, value=out["value"], unit="graphs/s", ms_per_step=out["ms_per_step"],
+                    edges_aggregated_per_s=out["edges_aggregated_per_s"], global_batch=out["config"]["global_batch"],
+                    graphs_per_rank_and_step=round(total_graphs / args.steps / world, 1))
+        out[args.scaling] = this
+        out[other["scaling"]] = other
     out.update(extra)
     print(json.dumps(out))
     if world > 1:

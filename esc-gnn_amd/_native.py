@@ -39,6 +39,18 @@ class BnFold(ctypes.Structure):
         "gamma", "beta", "mean", "invstd", "scale", "shift", "running_mean", "running_var")]
 
 
+class BnBwdFused(ctypes.Structure):
+    """mirror of `esc_bn_bwd_fused`: a BatchNorm(+ReLU) backward applied to the dY operand of a Linear backward"""
+    _fields_ = [("x", c_void_p), ("ld_x", c_int64)] + [(n, c_void_p) for n in ("mean", "invstd", "scale", "shift", "coef")] + \
+               [("relu", ctypes.c_int32)]
+
+
+class BnBwdNext(ctypes.Structure):
+    """mirror of `esc_bn_bwd_next`: column sums of the NEXT BatchNorm backward from the dX tiles"""
+    _fields_ = [("partial", c_void_p), ("x", c_void_p), ("ld_x", c_int64)] + \
+               [(n, c_void_p) for n in ("mean", "invstd", "scale", "shift")] + [("relu", ctypes.c_int32)]
+
+
 # name -> argtypes (every function returns int unless listed in _RET)
 SIGNATURES = {
     "esc_abi_version": [],
@@ -54,6 +66,7 @@ SIGNATURES = {
     "esc_bag_bwd_table_rows": [P, I64, I64, P, P, P, P, I64, I64, I64, I32, P, P, P],
     "esc_gine_aggregate_fwd": [P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P],
     "esc_gine_aggregate_bwd": [P, I64, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P],
+    "esc_gine_aggregate_bwd_deps_slots": [I64],
     "esc_reduce_sum": [P, I64, P, P],
     "esc_reduce_sum_jobs": [P, I32, P],
     "esc_segment_pool_fwd": [P, I64, P, I64, I64, I32, P, I64, P],
@@ -82,6 +95,12 @@ SIGNATURES = {
     "esc_linear_bwd_both": [P, I64, P, I64, P, P, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, P, P],
     "esc_linear_bwd_both_deferred": [P, I64, P, I64, P, P, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, P, P, P],
     "esc_slab_reduce_jobs": [P, I32, P],
+    "esc_linear_bwd_both_bn_ok": [P, I64, POINTER(BnBwdFused), P, I64, P, I64, I64, I64, I64, P, I64, P, POINTER(BnBwdNext)],
+    "esc_linear_bwd_bn_block_rows": [I64, I64, I64],
+    "esc_linear_bwd_both_bn": [P, I64, POINTER(BnBwdFused), P, I64, P, P, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, P, P,
+                               POINTER(BnBwdNext), P],
+    "esc_bn_bwd_coef": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, P, P, P, P],
+    "esc_bn_bwd_coef_from_partials": [P, I64, I64, I64, P, P, P, P],
     "esc_bn_scratch": [I64],
     "esc_bn_stats": [P, I64, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P, P],
     "esc_bn_stats_from_partials": [P, I64, I64, F32, F32, P, P, P, P, P, P, P, P, P],
@@ -136,7 +155,7 @@ SIGNATURES = {
     "esc_features_fill": [P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
 _RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_embed_plan_scratch": c_int64, "esc_prof_read_all": c_int64,
-        "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64,
+        "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64, "esc_linear_bwd_bn_block_rows": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64,
         "esc_zinc_workspace_floats": c_int64, "esc_ogb_workspace_floats": c_int64}
 

@@ -19,6 +19,8 @@
 // Algorithmic bytes/launch: 2*E*C*4 + 2*N*C*4 + E*8 + (N+1)*4.
 #include "common.h"
 
+#include <cstdlib>
+
 // Bitwise contract with the sequential CPU scatter: this file is compiled with -ffp-contract=off
 // (see Makefile) so a*b+c is never fused behind our back; explicit fmaf() calls still emit FMAs
 // where the order is free.
@@ -32,6 +34,18 @@ namespace esc {
 // graphs) costs ONE round of memory latency instead of one per leftover edge.
 constexpr int AGG_BATCH = 8;
 
+// VEC consecutive floats of a row <-> registers (16-, 8- or 4-byte accesses)
+template <int VEC> __device__ __forceinline__ void row_load(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) { const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+  else if constexpr (VEC == 2) { const float2 a = *reinterpret_cast<const float2*>(p); v[0] = a.x; v[1] = a.y; }
+  else v[0] = *p;
+}
+template <int VEC> __device__ __forceinline__ void row_store(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  else *p = v[0];
+}
+
 // AFF: x holds PRE-activation rows of a BatchNorm(+ReLU) whose output was never materialised; every row read applies
 // relu(x*xa_scale + xa_shift) on the fly (same fmaf + max as esc_affine_act, so the sums are bit-identical to the
 // materialised path) — the step engine's node chain loses one elementwise launch per layer.
@@ -43,17 +57,23 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
                                                     const int* __restrict__ in_src,
                                                     const float* __restrict__ eps_p, int N, int C,
                                                     float* __restrict__ out, int64_t ld_out,
-                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift) {
+                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift, int split) {
   ESC_PRIO();
-  const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  // split > 1: `split` waves share one destination row, each owning C / split consecutive columns.  A wave is three
+  // dependent memory round trips (segment pointers -> edge ids -> rows) for one row's worth of bytes: 2 400 one-shot waves
+  // on 1 024 SIMDs cannot hide them; twice the waves at half the bytes each can.  Every column still sums its edges in
+  // ascending order, so the result stays bit-identical to the sequential scatter.
+  const int wid = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  const int node = wid / split;
   if (node >= N) return;
+  const int cw = C / split, c_lo = (wid - node * split) * cw, c_hi = c_lo + cw;
   const int lane = lane_id();
   const int beg = uniform(in_ptr[node]);
   const int end = uniform(in_ptr[node + 1]);
   const bool has_self = eps_p != nullptr;           // nullptr: plain neighbour sum (GINE+ per-distance terms)
   const bool has_e = e != nullptr;                  // nullptr: message = relu(x_j)
   const float one_eps = has_self ? __fadd_rn(1.0f, *eps_p) : 0.f;
-  for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+  for (int c = c_lo + lane * VEC; c < c_hi; c += WAVE * VEC) {
     float acc[VEC], self[VEC], asc[VEC], ash[VEC];
 #pragma unroll
     for (int t = 0; t < VEC; ++t) { acc[t] = 0.f; asc[t] = 1.f; ash[t] = 0.f; }
@@ -62,13 +82,7 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
       for (int t = 0; t < VEC; ++t) { asc[t] = xa_scale[c + t]; ash[t] = xa_shift[c + t]; }
     }
     {
-      const float* ps = x + (size_t)node * ld_x + c;
-      if constexpr (VEC == 4) {
-        const float4 a = *reinterpret_cast<const float4*>(ps);
-        self[0] = a.x; self[1] = a.y; self[2] = a.z; self[3] = a.w;
-      } else {
-        self[0] = *ps;
-      }
+      row_load<VEC>(x + (size_t)node * ld_x + c, self);
       if constexpr (AFF) {
 #pragma unroll
         for (int t = 0; t < VEC; ++t) self[t] = fmaxf(fmaf(self[t], asc[t], ash[t]), 0.f);
@@ -83,13 +97,11 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
         const int s = uniform(in_src[jj]);
         const float* px = x + (size_t)s * ld_x + c;
         const float* pe = has_e ? e + (size_t)k * ld_e + c : px;
-        if constexpr (VEC == 4) {
-          const float4 a = *reinterpret_cast<const float4*>(px);
-          const float4 b = has_e ? *reinterpret_cast<const float4*>(pe) : make_float4(0.f, 0.f, 0.f, 0.f);
-          xv[u][0] = a.x; xv[u][1] = a.y; xv[u][2] = a.z; xv[u][3] = a.w;
-          ev[u][0] = b.x; ev[u][1] = b.y; ev[u][2] = b.z; ev[u][3] = b.w;
-        } else {
-          xv[u][0] = *px; ev[u][0] = has_e ? *pe : 0.f;
+        row_load<VEC>(px, xv[u]);
+        if (has_e) row_load<VEC>(pe, ev[u]);
+        else {
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) ev[u][t] = 0.f;
         }
       }
 #pragma unroll
@@ -108,10 +120,18 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = __fadd_rn(acc[t], __fmul_rn(one_eps, self[t]));
     }
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    else *po = acc[0];
+    row_store<VEC>(po, acc);
   }
 }
+
+// rows of exactly 256 floats (the hidden width of the reference, run_graphcount.py:465) may be split over two waves of 128
+// columns, 8 bytes per lane (see agg_fwd_wave).  Measured on a config-1 batch (profiles/r03_kernel_roofline.txt): forward
+// 7.2 -> 6.5 us with cold operands, 6.4 either way cache-resident: ON (ESC_AGG_SPLIT=1 switches it off); backward 11.8 -> 11.0
+// cold but 8.2 -> 9.3 with the operands the step has just produced: OFF (ESC_AGG_SPLIT_BWD=2 switches it on).
+static int g_agg_split = getenv("ESC_AGG_SPLIT") ? atoi(getenv("ESC_AGG_SPLIT")) : 2;
+static int g_agg_split_bwd = getenv("ESC_AGG_SPLIT_BWD") ? atoi(getenv("ESC_AGG_SPLIT_BWD")) : 1;
+static inline int agg_split(int64_t C) { return (g_agg_split == 2 && C == 256) ? 2 : 1; }
+static inline int agg_split_bwd(int64_t C) { return (g_agg_split_bwd == 2 && C == 256) ? 2 : 1; }
 
 // ---- narrow rows (C < 64, e.g. the 10-wide first layer): one thread per (node, channel) ----------
 __global__ __launch_bounds__(256) void agg_fwd_elem(const float* __restrict__ x, int64_t ld_x,
@@ -148,29 +168,25 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
                                                     float* __restrict__ d_e, int64_t ld_de,
                                                     float* __restrict__ dx, int64_t ld_dx, int accumulate_dx,
                                                     float* __restrict__ deps_part,
-                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift) {
+                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift, int split) {
   ESC_PRIO();
-  const int node = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  // split > 1: as in agg_fwd_wave — `split` waves share a source row, C / split columns each; deps_part then holds
+  // N * split partial dot products (wave w writes deps_part[w])
+  const int wid = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
+  const int node = wid / split;
   if (node >= N) return;
+  const int cw = C / split, c_lo = (wid - node * split) * cw, c_hi = c_lo + cw;
   const int lane = lane_id();
   const int beg = uniform(out_ptr[node]);
   const int end = uniform(out_ptr[node + 1]);
   const bool has_self = eps_p != nullptr, has_e = e != nullptr;
   const float one_eps = has_self ? 1.0f + *eps_p : 0.f;
   float dot = 0.f;
-  for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+  for (int c = c_lo + lane * VEC; c < c_hi; c += WAVE * VEC) {
     float xi[VEC], gi[VEC], acc[VEC];
     {
-      const float* px = x + (size_t)node * ld_x + c;
-      const float* pg = g + (size_t)node * ld_g + c;
-      if constexpr (VEC == 4) {
-        const float4 a = *reinterpret_cast<const float4*>(px);
-        const float4 b = *reinterpret_cast<const float4*>(pg);
-        xi[0] = a.x; xi[1] = a.y; xi[2] = a.z; xi[3] = a.w;
-        gi[0] = b.x; gi[1] = b.y; gi[2] = b.z; gi[3] = b.w;
-      } else {
-        xi[0] = *px; gi[0] = *pg;
-      }
+      row_load<VEC>(x + (size_t)node * ld_x + c, xi);
+      row_load<VEC>(g + (size_t)node * ld_g + c, gi);
       if constexpr (AFF) {                                  // x is the pre-activation row: the layer input is relu(x*scale+shift)
 #pragma unroll
         for (int t = 0; t < VEC; ++t) xi[t] = fmaxf(fmaf(xi[t], xa_scale[c + t], xa_shift[c + t]), 0.f);
@@ -188,14 +204,12 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
         const int d = uniform(out_dst[jj]);
         const float* pg = g + (size_t)d * ld_g + c;
         const float* pe = has_e ? e + (size_t)kk[u] * ld_e + c : pg;
-        if constexpr (VEC == 4) {
-          const float4 a = has_e ? *reinterpret_cast<const float4*>(pe) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 b = *reinterpret_cast<const float4*>(pg);
-          ev[u][0] = a.x; ev[u][1] = a.y; ev[u][2] = a.z; ev[u][3] = a.w;
-          gv[u][0] = b.x; gv[u][1] = b.y; gv[u][2] = b.z; gv[u][3] = b.w;
-        } else {
-          ev[u][0] = has_e ? *pe : 0.f; gv[u][0] = *pg;
+        if (has_e) row_load<VEC>(pe, ev[u]);
+        else {
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) ev[u][t] = 0.f;
         }
+        row_load<VEC>(pg, gv[u]);
       }
 #pragma unroll
       for (int u = 0; u < AGG_BATCH; ++u) {
@@ -206,33 +220,25 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
             o[t] = ((has_e ? __fadd_rn(xi[t], ev[u][t]) : xi[t]) > 0.f) ? gv[u][t] : 0.f;
             acc[t] += o[t];
           }
-          if (d_e != nullptr) {
-            float* pd = d_e + (size_t)kk[u] * ld_de + c;
-            if constexpr (VEC == 4) *reinterpret_cast<float4*>(pd) = make_float4(o[0], o[1], o[2], o[3]);
-            else *pd = o[0];
-          }
+          if (d_e != nullptr) row_store<VEC>(d_e + (size_t)kk[u] * ld_de + c, o);
         }
       }
     }
     if (dx != nullptr) {
       float* po = dx + (size_t)node * ld_dx + c;
-      if constexpr (VEC == 4) {
-        float4 o = make_float4(fmaf(one_eps, gi[0], acc[0]), fmaf(one_eps, gi[1], acc[1]),
-                               fmaf(one_eps, gi[2], acc[2]), fmaf(one_eps, gi[3], acc[3]));
-        if (accumulate_dx) {
-          const float4 prev = *reinterpret_cast<const float4*>(po);
-          o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
-        }
-        *reinterpret_cast<float4*>(po) = o;
-      } else {
-        const float o = fmaf(one_eps, gi[0], acc[0]);
-        *po = accumulate_dx ? *po + o : o;
+      float o[VEC], prev[VEC];
+      if (accumulate_dx) row_load<VEC>(po, prev);
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) {
+        o[t] = fmaf(one_eps, gi[t], acc[t]);
+        if (accumulate_dx) o[t] += prev[t];
       }
+      row_store<VEC>(po, o);
     }
   }
   if (deps_part != nullptr) {
     dot = wave_sum(dot);
-    if (lane == 0) deps_part[node] = dot;
+    if (lane == 0) deps_part[wid] = dot;
   }
 }
 
@@ -359,10 +365,12 @@ int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t
     const bool vec = (C % 4 == 0) && (ld_x % 4 == 0) && (!e || ld_e % 4 == 0) && (ld_out % 4 == 0) &&
                      esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(out);
     const int64_t blocks = esc::cdiv(N, 4);
-    if (vec)
-      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr);
+    if (vec && esc::agg_split(C) == 2)
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<2, false>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 2);
+    else if (vec)
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 1);
     else
-      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 1);
   } else {
     const int64_t blocks = esc::cdiv(N * C, 256);
     esc::launch(-1, esc::agg_fwd_elem, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
@@ -370,6 +378,9 @@ int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t
   ESC_CHECK_LAUNCH("esc_gine_aggregate_fwd");
   return ESC_OK;
 }
+
+/* deps_part entries per node the backward writes for rows of C floats (1, or 2 when the row is split over two waves) */
+int esc_gine_aggregate_bwd_deps_slots(int64_t C) { return esc::agg_split_bwd(C); }
 
 int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t ld_e,
                            const float* g, int64_t ld_g, const int32_t* out_ptr,
@@ -388,10 +399,12 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                    (!dx || ld_dx % 4 == 0) && esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(g) &&
                    (!d_e || esc::aligned16(d_e)) && (!dx || esc::aligned16(dx));
   const int64_t blocks = esc::cdiv(N, 4);
-  if (vec)
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr);
+  if (vec && esc_gine_aggregate_bwd_deps_slots(C) == 2)
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<2, false>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 2);
+  else if (vec)
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 1);
   else
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 1);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd");
   return ESC_OK;
 }
@@ -408,8 +421,12 @@ int esc_gine_aggregate_fwd_affine(const float* x, int64_t ld_x, const float* x_s
   ESC_REQUIRE(esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(out), "esc_gine_aggregate_fwd_affine: pointers must be 16-byte aligned");
   if (N == 0) return ESC_OK;
   ESC_REQUIRE(in_edge && in_src, "esc_gine_aggregate_fwd_affine: null edge arrays");
-  esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, in_ptr,
-              in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift);
+  if (esc::agg_split(C) == 2)
+    esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<2, true>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, in_ptr,
+                in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift, 2);
+  else
+    esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, in_ptr,
+                in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift, 1);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_fwd_affine");
   return ESC_OK;
 }
@@ -427,8 +444,12 @@ int esc_gine_aggregate_bwd_affine(const float* x, int64_t ld_x, const float* x_s
               "esc_gine_aggregate_bwd_affine: pointers must be 16-byte aligned");
   if (N == 0) return ESC_OK;
   ESC_REQUIRE(out_edge && out_dst, "esc_gine_aggregate_bwd_affine: null edge arrays");
-  esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, g, ld_g,
-              out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift);
+  if (esc_gine_aggregate_bwd_deps_slots(C) == 2)
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<2, true>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, g, ld_g,
+                out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift, 2);
+  else
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, g, ld_g,
+                out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift, 1);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd_affine");
   return ESC_OK;
 }

@@ -197,4 +197,31 @@ __device__ __forceinline__ void bn_fold_column(const BnFoldDev& f, int col, bool
   }
 }
 
+// BatchNorm(+ReLU) BACKWARD applied to the A operand while it is staged (PRO bit 2): A holds the gradient dOut of the
+// BatchNorm's output, `x` the rows the BatchNorm normalised (same shape as A), and the operand the MFMAs see is
+//   dY = scale * (g - k1 - (x - mean) * invstd * k2),   g = dOut * [fmaf(x, scale, shift) > 0]   (relu; g = dOut otherwise)
+// with (k1, k2) = coef = (sum g, sum g*xhat) / rows — the value esc_bn_bwd_apply would have written to memory for the
+// GEMM to read back.  The elementwise launch between the finalize and the GEMM disappears from the dependent chain.
+struct BnbDev {
+  const float* x; int ldx;
+  const float* mean; const float* invstd; const float* scale; const float* shift;
+  const float2* coef;
+  int relu;
+};
+// ... and the column sums (sum g, sum g*xhat) of the NEXT BatchNorm backward, taken over the rows of every output tile in
+// the epilogue (PRO bit 3): C is the gradient of that BatchNorm's output, `x` what it normalised; partial[tile_m][col].
+struct BnStatDev {
+  float2* partial;
+  const float* x; int ldx;
+  const float* mean; const float* invstd; const float* scale; const float* shift;
+  int relu;
+};
+
+// one element: gradient `gv` of the BatchNorm output, its input `xv`, channel coefficients mu = mean, a = scale,
+// (ms, mh) = the mask's affine (0, 1 without activation), k1 = sum g / rows, k2 = invstd * sum g*xhat / rows
+__device__ __forceinline__ float bnb_apply(float gv, float xv, float mu, float a, float ms, float mh, float k1, float k2) {
+  const float gm = fmaf(xv, ms, mh) > 0.f ? gv : 0.f;
+  return a * fmaf(mu - xv, k2, gm - k1);                               // = a * (g - k1 - (x - mu) * invstd * k2)
+}
+
 }  // namespace esc

@@ -30,7 +30,7 @@ struct Arena {
   }
 };
 
-struct BnWs { float *mean, *invstd, *scale, *shift, *nglob; };     // nglob: rows over all ranks (SyncBN)
+struct BnWs { float *mean, *invstd, *scale, *shift, *nglob, *coef; };     // nglob: rows over all ranks (SyncBN); coef: float2[C] of the backward
 struct MlpWs { float *Y0, *Y1; BnWs b0, b1; float* A1 = nullptr; };   // A1: materialised hidden activation (ELU models)
 
 struct Layout {
@@ -46,6 +46,7 @@ struct Layout {
   float *bn_scratch, *bag_scratch, *slabs;
   float *col_stats;               // GEMM-epilogue BatchNorm partials: float2[ceil(rows/32)][H]
   float *col_stats_b;             // second set: a folded BatchNorm's partials live until its consumer has run
+  float *bst_part;                // BatchNorm-backward column sums left by a dX epilogue / an aggregate backward: float2[slots][H]
   // private scratch of the x_embedding branch (runs on a side stream next to the z/conv chain)
   float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
   float *bn_scratch_e, *col_stats_e;   // the edge stream's own BatchNorm scratch / GEMM-epilogue partials
@@ -56,7 +57,7 @@ struct Layout {
   int64_t total;
 };
 
-static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); w.nglob = a.take(16); return w; }
+static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); w.nglob = a.take(16); w.coef = a.take(2 * C); return w; }
 
 static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z, float* base, bool train) {
   Layout y{};
@@ -87,12 +88,13 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   y.bn_scratch_e = a.take(esc_bn_scratch(H));
   y.col_stats_e = a.take(2 * (E / 32 + 1) * H);
   if (train) {
+    y.bst_part = a.take(2 * (N / 16 + 2) * H);
     y.dT1x = a.take(N * H); y.dT2x = a.take(N * H);
     y.slabs_x = a.take(esc_linear_bwd_weight_scratch(N, H, H));
     y.dcat = a.take(N * y.W); y.dAl = a.take(N * H); y.dT1 = a.take(N * H); y.dT2 = a.take(N * H);
     y.dagg = a.take(N * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
     for (int l = 0; l < L; ++l) y.d_e[l] = a.take(E * (l == 0 ? C0 : H));
-    y.deps_part = a.take(N * (L > 0 ? L : 1));        // one vector per GINE layer, summed together at the end
+    y.deps_part = a.take(2 * N * (L > 0 ? L : 1));        // one vector per GINE layer, summed together at the end
     y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
     // one private slab region per weight gradient: their ordered reduces are deferred to ONE launch at the end
     int64_t sl = esc_linear_bwd_weight_scratch(E, H, H) + 64;                        // zlin
@@ -150,6 +152,30 @@ static int linear_backward(const Ctx& c, const float* dY, int64_t ld_dy, const f
   c.jobs->emplace_back();
   return esc_linear_bwd_both_deferred(dY, ld_dy, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db,
                                       slabs, &c.jobs->back(), c.s);
+}
+
+// ---- BatchNorm(+ReLU) backward folded into the Linear backward behind it (r03; esc_linear_bwd_both_bn) ------------------
+// The node chain's backward was, per Linear -> BatchNorm -> ReLU pair, partial -> finalize -> apply -> dX+dW: four dependent
+// launches.  The apply now happens while the GEMM stages its dY operand (bit 0) and the column sums of an MLP's FIRST
+// BatchNorm come out of the dX epilogue of its second Linear (bit 1): partial/finalize -> dX+dW -> finalize -> dX+dW.
+// ESC_BN_FUSE_BWD=0 restores the elementwise launches (A/B runs, bisecting).
+static int g_bn_fuse_bwd = getenv("ESC_BN_FUSE_BWD") ? atoi(getenv("ESC_BN_FUSE_BWD")) : 3;
+static esc_bn_bwd_fused bn_fused(const float* x, int64_t ld_x, const BnWs& w, int relu) {
+  return esc_bn_bwd_fused{x, ld_x, w.mean, w.invstd, w.scale, w.shift, w.coef, relu};
+}
+static int linear_backward_bn(const Ctx& c, const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused& f, const float* X, int64_t ld_x,
+                              const float* sc, const float* sh, const esc_linear_t& lin, int64_t M, float* dX, int64_t ld_dx,
+                              int accumulate, const esc_bn_bwd_next* next) {
+  const LdsFloorGuard cap(c.on_edge_stream);
+  const int64_t N = lin.out_dim, K = lin.in_dim;
+  if (c.jobs == nullptr)
+    return esc_linear_bwd_both_bn(dOut, ld_dout, &f, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db, c.y.slabs,
+                                  nullptr, next, c.s);
+  float* slabs = *c.slab_cursor;
+  *c.slab_cursor += (esc_linear_bwd_weight_scratch(M, N, K) + 63) & ~63LL;
+  c.jobs->emplace_back();
+  return esc_linear_bwd_both_bn(dOut, ld_dout, &f, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db, slabs,
+                                &c.jobs->back(), next, c.s);
 }
 
 // The x_embedding MLP depends only on x (forward) / on d(cat)[:, 0:H] (backward): five to eight small,
@@ -274,6 +300,7 @@ static void mark(int which, void* stream) {
   (void)hipEventRecord(e, (hipStream_t)stream);
 }
 
+static int g_e0_early = getenv("ESC_E0_EARLY") ? atoi(getenv("ESC_E0_EARLY")) : 1;   // see forward()
 static int g_fuse_finalize = 1; // ... and their merge by the GEMM's last workgroup (no bn_finalize launch)
 static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's epilogue (no extra pass over Y)
 // Node-sized BatchNorms: partials merged in the consumer's prologue instead of a finalize launch (esc_engine_set_gemm_stats
@@ -317,8 +344,7 @@ static int sync_allreduce(const Ctx& c, float* buf, int64_t n) {
 }
 // w.mean / w.invstd hold THIS rank's statistics over its M rows: replace them (and the consumer-side coefficients, the
 // running statistics) by the statistics over all ranks' rows
-static int bn_sync_forward(const Ctx& c, int64_t M, const esc_bn_t& bn, const BnWs& w) {
-  const int64_t C = c.y.H;
+static int bn_sync_forward(const Ctx& c, int64_t M, const esc_bn_t& bn, const BnWs& w, int64_t C) {
   float* buf = sync_buf(c);
   ESC_TRY(esc_bn_sync_pack(w.mean, w.invstd, M, bn.eps, C, g_coll.rank, g_coll.world, buf, c.s));
   ESC_TRY(sync_allreduce(c, buf, (int64_t)g_coll.world * 3 * C));
@@ -382,13 +408,13 @@ static int linear_bn(const Ctx& c, const float* X, int64_t ld_x, const esc_linea
                                             bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
                                             sync ? nullptr : bn.running_var, bn.gamma, bn.beta, sync ? nullptr : w.scale,
                                             sync ? nullptr : w.shift, c.s));
-    return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
+    return sync ? bn_sync_forward(c, M, bn, w, H) : ESC_OK;
   }
   if (c.train) {
     ESC_TRY(esc_bn_stats(Y, ld_y, M, H, bn.eps, bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
                          sync ? nullptr : bn.running_var, bn.gamma, bn.beta, sync ? nullptr : w.scale, sync ? nullptr : w.shift,
                          c.y.bn_scratch, c.s));
-    return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
+    return sync ? bn_sync_forward(c, M, bn, w, H) : ESC_OK;
   }
   return esc_bn_eval_coef(bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, H, w.scale, w.shift, c.s);
 }
@@ -400,7 +426,7 @@ static int bn_coeffs(const Ctx& c, const float* X, int64_t ld, int64_t M, const 
     ESC_TRY(esc_bn_stats(X, ld, M, C, bn.eps, bn.momentum, w.mean, w.invstd, sync ? nullptr : bn.running_mean,
                          sync ? nullptr : bn.running_var, bn.gamma, bn.beta, sync ? nullptr : w.scale, sync ? nullptr : w.shift,
                          c.y.bn_scratch, c.s));
-    return sync ? bn_sync_forward(c, M, bn, w) : ESC_OK;
+    return sync ? bn_sync_forward(c, M, bn, w, C) : ESC_OK;
   }
   return esc_bn_eval_coef(bn.running_mean, bn.running_var, bn.gamma, bn.beta, bn.eps, C, w.scale, w.shift, c.s);
 }
@@ -445,13 +471,71 @@ static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const f
 }
 
 // given dOut (grad of the materialised output `out`), produce parameter grads and, if dA != NULL, dA
-static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
-                        const float* out, int64_t ld_out, const float* dOut, int64_t ld_dout, float* dA,
-                        int64_t ld_da, bool pre_out = false) {
+// will mlp_backward take the fused form (see g_bn_fuse_bwd)?  ReLU MLPs whose hidden activation was never materialised,
+// statistics of this rank only, shapes the fused kernels serve
+static bool mlp_backward_fused(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M, const float* out,
+                               int64_t ld_out, const float* dOut, int64_t ld_dout, const float* dA, int64_t ld_da, bool pre_out) {
   const Layout& y = c.y;
   const int64_t H = y.H;
+  if (!((g_bn_fuse_bwd & 1) && c.train && c.act == 1 && w.A1 == nullptr && !sync_on(c) && y.bst_part != nullptr && p.lin1.in_dim == H && p.lin1.out_dim == H))
+    return false;
+  const esc_bn_bwd_fused f1 = bn_fused(pre_out ? out : w.Y1, pre_out ? ld_out : H, w.b1, 1), f0 = bn_fused(w.Y0, H, w.b0, 1);
+  const esc_bn_bwd_next n0{y.bst_part, w.Y0, H, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, 1};
+  const float* slab_probe = c.jobs ? *c.slab_cursor : y.slabs;
+  return esc_linear_bwd_both_bn_ok(dOut, ld_dout, &f1, w.Y0, H, p.lin1.w, H, M, H, H, y.dT2, H, slab_probe, (g_bn_fuse_bwd & 2) ? &n0 : nullptr) != 0 &&
+         esc_linear_bwd_both_bn_ok(y.dT2, H, &f0, A, ld_a, p.lin0.w, p.lin0.in_dim, M, H, p.lin0.in_dim, dA, ld_da, slab_probe, nullptr) != 0;
+}
+// have_slots > 0: the column sums of BatchNorm 1's backward are already in c.y.bst_part (float2[have_slots][H], left by the
+// producer of dOut: the readout's dX epilogue or the next layer's aggregate backward)
+static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M,
+                        const float* out, int64_t ld_out, const float* dOut, int64_t ld_dout, float* dA,
+                        int64_t ld_da, bool pre_out = false, int64_t have_slots = 0) {
+  const Layout& y = c.y;
+  const int64_t H = y.H;
+  if (mlp_backward_fused(c, p, w, A, ld_a, M, out, ld_out, dOut, ld_dout, dA, ld_da, pre_out)) {
+    {
+      const float* x1 = pre_out ? out : w.Y1;                  // what BatchNorm 1 normalised
+      const int64_t ld_x1 = pre_out ? ld_out : H;
+      const esc_bn_bwd_fused f1 = bn_fused(x1, ld_x1, w.b1, 1), f0 = bn_fused(w.Y0, H, w.b0, 1);
+      esc_bn_bwd_next n0{y.bst_part, w.Y0, H, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, 1};
+      const bool stats = (g_bn_fuse_bwd & 2) != 0;
+      if (have_slots > 0)
+        ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, have_slots, M, H, w.b1.coef, p.bn1.dgamma, p.bn1.dbeta, c.s));
+      else
+        ESC_TRY(esc_bn_bwd_coef(x1, ld_x1, nullptr, 0, dOut, ld_dout, M, H, w.b1.mean, w.b1.invstd, p.bn1.gamma, p.bn1.beta, 1, w.b1.coef,
+                                p.bn1.dgamma, p.bn1.dbeta, y.bn_scratch, c.s));
+      ESC_TRY(linear_backward_bn(c, dOut, ld_dout, f1, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1, M, y.dT2, H, 0, stats ? &n0 : nullptr));
+      if (stats)
+        ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, cdiv(M, esc_linear_bwd_bn_block_rows(M, H, H)), M, H, w.b0.coef, p.bn0.dgamma, p.bn0.dbeta, c.s));
+      else
+        ESC_TRY(esc_bn_bwd_coef(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, 1, w.b0.coef,
+                                p.bn0.dgamma, p.bn0.dbeta, y.bn_scratch, c.s));
+      return linear_backward_bn(c, y.dT2, H, f0, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0, nullptr);
+    }
+  }
   if (pre_out) ESC_TRY(bn_backward(c, out, ld_out, nullptr, 0, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));   // `out` = pre-BN rows
   else         ESC_TRY(bn_backward(c, w.Y1, H, out, ld_out, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));
+  // bit 1 alone: the elementwise apply launches stay, only the column sums of BatchNorm 0 come out of lin1's dX epilogue
+  if ((g_bn_fuse_bwd & 3) == 2 && c.train && c.act == 1 && w.A1 == nullptr && !sync_on(c) && y.bst_part != nullptr && p.lin1.in_dim == H && p.lin1.out_dim == H) {
+    esc_bn_bwd_next n0{y.bst_part, w.Y0, H, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, 1};
+    const float* slab_probe = c.jobs ? *c.slab_cursor : y.slabs;
+    if (esc_linear_bwd_both_bn_ok(y.dT1, H, nullptr, w.Y0, H, p.lin1.w, H, M, H, H, y.dT2, H, slab_probe, &n0)) {
+      const LdsFloorGuard cap(c.on_edge_stream);
+      float* slabs = y.slabs;
+      esc_reduce_job* job = nullptr;
+      if (c.jobs) {
+        slabs = *c.slab_cursor;
+        *c.slab_cursor += (esc_linear_bwd_weight_scratch(M, H, H) + 63) & ~63LL;
+        c.jobs->emplace_back();
+        job = &c.jobs->back();
+      }
+      ESC_TRY(esc_linear_bwd_both_bn(y.dT1, H, nullptr, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1.w, H, M, H, H, y.dT2, H, 0, p.lin1.dw, H, p.lin1.db,
+                                     slabs, job, &n0, c.s));
+      ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, cdiv(M, esc_linear_bwd_bn_block_rows(M, H, H)), M, H, w.b0.coef, p.bn0.dgamma, p.bn0.dbeta, c.s));
+      ESC_TRY(esc_bn_bwd_apply(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, 1, w.b0.coef, y.dT2, H, c.s));
+      return linear_backward(c, y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0);
+    }
+  }
   if (w.A1) {
     ESC_TRY(linear_backward(c, y.dT1, H, w.A1, H, nullptr, nullptr, p.lin1, M, y.dT2, H, 0));
     ESC_TRY(bn_backward(c, w.Y0, H, w.A1, H, y.dT2, H, M, w.b0, p.bn0, y.dT2, H, y.bn_scratch));
@@ -484,6 +568,15 @@ static int forward(const Ctx& c) {
   } else {
     ESC_TRY(linear_bn(ce, y.Zb, H, m->zlin, y.zb0.scale, y.zb0.shift, E, y.Yz, m->zbn1, y.zb1));
   }                                                                       // z_emb = relu(Yz*scale+shift)
+  // The first edge term is narrow (in_dim columns: a bandwidth pass over z_emb): it applies z_embedding's last BatchNorm+ReLU to
+  // its operand itself and runs BEFORE the pass that materialises z_emb for the wide layers — the node chain's first
+  // aggregate waits for e_0 only (same fmaf + max per element: e_0 is bit-identical either way)
+  const bool e0_early = mat && g_e0_early && y.C0 <= 32 && L >= 1;
+  if (e0_early) {
+    const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
+    ESC_TRY(esc_linear_fwd(y.Yz, H, m->conv[0].lin.w, H, m->conv[0].lin.b, y.zb1.scale, y.zb1.shift, E, y.C0, H, y.e[0], y.C0, nullptr, ce.s));
+    if (es.ok && hipEventRecord(es.e_ready[0], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+  }
   if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, ce.s));
   // The edge terms run one layer ahead of the node chain: e_{l+1} is queued behind the aggregate of layer l and overlaps
   // that layer's MLP, so that a bandwidth-bound aggregate never shares the HBM with an edge-sized GEMM (both would only
@@ -500,7 +593,7 @@ static int forward(const Ctx& c) {
   };
   mark(PH_START, c.s);
   const int ahead = es.ok ? g_edge_ahead : (int)L;          // one stream: all of them up front, in layer order
-  for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
+  for (int l = e0_early ? 1 : 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
   // ---- node pipeline (first, while it would otherwise wait for the first edge term: the chunk schedule of the bag
   // gradient, which depends on the batch's index arrays only)
   if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, c.s));
@@ -583,31 +676,59 @@ static int backward(const Ctx& c, Pending* defer) {
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W;
   // lin2 <- dpred
   ESC_TRY(linear_backward(c, y.dpred, 1, y.Yl, H, y.bl.scale, y.bl.shift, m->lin2, N, y.dAl, H, 0));
-  ESC_TRY(bn_backward(c, y.Yl, H, nullptr, 0, y.dAl, H, N, y.bl, m->bn_lin1, y.dAl, H, y.bn_scratch));
+  // bn_lin1 backward: folded into lin1's backward when the fused kernels serve its column blocks (see g_bn_fuse_bwd)
+  EdgeStream& es = edge_stream();
+  const bool split_lin1 = es.ok && c.jobs != nullptr && L >= 1;
+  const esc_bn_bwd_fused fl = bn_fused(y.Yl, H, y.bl, 1);
+  const bool fa_l = fuse_node_act(c);
+  // the last layer's output gradient d(cat)[:, L*H:] is final once lin1's node-side block has written it: its dX tiles
+  // leave the column sums of that layer's last BatchNorm backward (bit 1)
+  const MlpWs& wl = y.conv[L > 0 ? L - 1 : 0];
+  esc_bn_bwd_next nl{y.bst_part, y.cat + L * H, W, wl.b1.mean, wl.b1.invstd, wl.b1.scale, wl.b1.shift, 1};
+  auto lin1_ok = [&](int64_t col0, int64_t ncols, const esc_bn_bwd_next* nx) {
+    return esc_linear_bwd_both_bn_ok(y.dAl, H, &fl, y.cat + col0, W, m->lin1.w + col0, W, N, H, ncols, y.dcat + col0, W,
+                                     c.jobs ? *c.slab_cursor : y.slabs, nx) != 0;
+  };
+  const bool fuse_l = (g_bn_fuse_bwd & 1) && c.act == 1 && !sync_on(c) && y.bst_part != nullptr &&
+                      (split_lin1 ? (lin1_ok(0, L * H, nullptr) && lin1_ok(L * H, H, nullptr)) : lin1_ok(0, W, nullptr));
+  int64_t last_slots = 0;          // > 0: slots of bst_part that hold the last layer's BatchNorm-backward sums
+  if (fuse_l)
+    ESC_TRY(esc_bn_bwd_coef(y.Yl, H, nullptr, 0, y.dAl, H, N, H, y.bl.mean, y.bl.invstd, m->bn_lin1.gamma, m->bn_lin1.beta, 1, y.bl.coef,
+                            m->bn_lin1.dgamma, m->bn_lin1.dbeta, y.bn_scratch, c.s));
+  else
+    ESC_TRY(bn_backward(c, y.Yl, H, nullptr, 0, y.dAl, H, N, y.bl, m->bn_lin1, y.dAl, H, y.bn_scratch));
   // lin1 backward.  The node chain needs d(cat)[:, L*H:] (the last layer's output gradient) at once and the other
   // slices only when the first aggregate backward accumulates into them ~60 us later: with an edge stream the last
   // column block (dX slice + its dW columns) is computed here and the other L blocks over there, concurrently.
-  EdgeStream& es = edge_stream();
-  const bool split_lin1 = es.ok && c.jobs != nullptr && L >= 1;
   if (split_lin1) {
     const int64_t K0 = L * H;                                 // columns [0, K0) go to the edge stream
-    auto part = [&](void* stream, int64_t col0, int64_t ncols, float* db) -> int {
+    auto part = [&](void* stream, int64_t col0, int64_t ncols, float* db, const esc_bn_bwd_next* nx) -> int {
       float* slabs = *c.slab_cursor;
       *c.slab_cursor += (esc_linear_bwd_weight_scratch(N, H, ncols) + 63) & ~63LL;
       c.jobs->emplace_back();
-      const bool fa = fuse_node_act(c);
+      const bool fa = fa_l;
+      if (fuse_l)
+        return esc_linear_bwd_both_bn(y.dAl, H, &fl, y.cat + col0, W, fa ? y.cat_scale + col0 : nullptr, fa ? y.cat_shift + col0 : nullptr, m->lin1.w + col0, W,
+                                      N, H, ncols, y.dcat + col0, W, 0, m->lin1.dw + col0, W, db, slabs, &c.jobs->back(), nx, stream);
       return esc_linear_bwd_both_deferred(y.dAl, H, y.cat + col0, W, fa ? y.cat_scale + col0 : nullptr, fa ? y.cat_shift + col0 : nullptr, m->lin1.w + col0, W, N, H, ncols,
                                           y.dcat + col0, W, 0, m->lin1.dw + col0, W, db, slabs, &c.jobs->back(), stream);
     };
     ESC_TRY(chain(es.lin1_fork, (hipStream_t)c.s, es.stream));
     {
       const LdsFloorGuard cap(true);
-      ESC_TRY(part(es.stream, 0, K0, nullptr));
+      ESC_TRY(part(es.stream, 0, K0, nullptr, nullptr));
     }
     if (hipEventRecord(es.lin1_rest, es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
-    ESC_TRY(part(c.s, K0, H, m->lin1.db));
+    // (the last layer's MLP backward follows at once: does it take the fused form, and can this block leave its sums?)
+    const bool leave = fuse_l && fa_l && (g_bn_fuse_bwd & 2) && lin1_ok(K0, H, &nl) &&
+                       mlp_backward_fused(c, m->conv[L - 1].nn, y.conv[L - 1], y.agg[L - 1], L == 1 ? y.C0 : H, N, y.cat + L * H, W, y.dcat + L * H, W,
+                                          y.dagg, L == 1 ? y.C0 : H, true);
+    ESC_TRY(part(c.s, K0, H, m->lin1.db, leave ? &nl : nullptr));
+    if (leave) last_slots = cdiv(N, esc_linear_bwd_bn_block_rows(N, H, H));
+  } else if (fuse_l) {
+    ESC_TRY(linear_backward_bn(c, y.dAl, H, fl, y.cat, W, fa_l ? y.cat_scale : nullptr, fa_l ? y.cat_shift : nullptr, m->lin1, N, y.dcat, W, 0, nullptr));
   } else {
-    ESC_TRY(linear_backward(c, y.dAl, H, y.cat, W, fuse_node_act(c) ? y.cat_scale : nullptr, fuse_node_act(c) ? y.cat_shift : nullptr, m->lin1, N, y.dcat, W, 0));
+    ESC_TRY(linear_backward(c, y.dAl, H, y.cat, W, fa_l ? y.cat_scale : nullptr, fa_l ? y.cat_shift : nullptr, m->lin1, N, y.dcat, W, 0));
   }
   // x_embedding backward (input x needs no gradient): only reads d(cat)[:, 0:H] -> side stream
   SideStream& ss = side_stream();
@@ -636,18 +757,18 @@ static int backward(const Ctx& c, Pending* defer) {
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
     ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W,
-                         y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C, fuse_node_act(c)));
+                         y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C, fuse_node_act(c), l == (int)L - 1 ? last_slots : 0));
     float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
     if (split_lin1 && l == (int)L - 1 &&                               // ... which the edge stream's lin1 blocks fill
         hipStreamWaitEvent((hipStream_t)c.s, es.lin1_rest, 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     if (fuse_node_act(c) && l > 0)
       ESC_TRY(esc_gine_aggregate_bwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], C, y.dagg, C,
                                             b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C, y.d_e[l], C, dx, W, 1,
-                                            y.deps_part + (int64_t)l * N, c.s));
+                                            y.deps_part + (int64_t)l * 2 * N, c.s));
     else
       ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
-                                     y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * N, c.s));
-    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
+                                     y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * 2 * N, c.s));
+    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * 2 * N, N * esc_gine_aggregate_bwd_deps_slots(C), cv.deps});
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));   // lin_l backward: edge stream
     const float* zin = g_materialise_edge_act ? y.Zemb : y.Yz;
     const float* zsc = g_materialise_edge_act ? nullptr : y.zb1.scale;
@@ -667,9 +788,9 @@ static int backward(const Ctx& c, Pending* defer) {
     } else {
       ESC_TRY(linear_backward(ce, y.d_e[l], C, zin, H, zsc, zsh, cv.lin, E, y.dZemb, H, l == (int)L - 1 ? 0 : 1));
     }
-    if (es.ok && !edge_jobs.empty()) {      // the edge stream now idles until d_e of the next layer: reduce these slabs there
-      ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));
-      edge_jobs.clear();
+    if (es.ok && !edge_jobs.empty() && l > 0) {      // the edge stream now idles until d_e of the next layer: reduce these slabs there
+      ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));   // (l == 0: the tail of the step follows at
+      edge_jobs.clear();                                                                    // once — its slabs wait for the final reduce)
     }
   }
   if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0, fuse_node_act(c)));
@@ -739,7 +860,7 @@ static Layout plan_layout_zinc(const esc_zinc_gin_t* m, int64_t N, int64_t E, in
     y.dT1 = a.take(N * H); y.dT2 = a.take(N * H); y.dagg = a.take(N * H); y.dX0 = a.take(N * C0);
     y.dZcat = a.take(E * y.Wz); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
     for (int l = 0; l < L; ++l) y.d_e[l] = a.take(E * (l == 0 ? C0 : H));
-    y.deps_part = a.take(N * (L > 0 ? L : 1));
+    y.deps_part = a.take(2 * N * (L > 0 ? L : 1));
     y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
     int64_t sl = esc_linear_bwd_weight_scratch(E, H, H) + 64;                                    // zlin
     for (int l = 0; l < L; ++l) {
@@ -843,8 +964,8 @@ static int backward_zinc(const ZincCtx& z) {
     ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)l * H, W, y.dcat + (int64_t)l * H, W, y.dagg, C));
     float* dx = l == 0 ? y.dX0 : y.dcat + (int64_t)(l - 1) * H;
     ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
-                                   y.d_e[l], C, dx, l == 0 ? C0 : W, l == 0 ? 0 : 1, y.deps_part + (int64_t)l * N, c.s));
-    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, cv.deps});
+                                   y.d_e[l], C, dx, l == 0 ? C0 : W, l == 0 ? 0 : 1, y.deps_part + (int64_t)l * 2 * N, c.s));
+    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * 2 * N, N * esc_gine_aggregate_bwd_deps_slots(C), cv.deps});
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));      // conv.lin backward: edge stream
     ESC_TRY(linear_backward(ce, y.d_e[l], C, y.Zcat, Wz, nullptr, nullptr, cv.lin, E, y.dZcat, Wz, l == (int)L - 1 ? 0 : 1));
   }
@@ -955,7 +1076,7 @@ static OgbLayout plan_layout_ogb(const esc_ogb_gnn_t* m, int64_t N, int64_t E, i
     y.dvn_a = a.take(G * H); y.dvn_b = a.take(G * H); y.dG1 = a.take(G * H2); y.dG2 = a.take(G * H); y.dtmp = a.take(G * H);
     y.poolG = a.take(G * H);
     for (int l = 0; l < L; ++l) y.l[l].d_e = a.take(E * H);
-    y.deps_part = a.take(N * (L > 0 ? L : 1));
+    y.deps_part = a.take(2 * N * (L > 0 ? L : 1));
     y.bag_scratch = a.take(esc_bag_bwd_scratch(Z, H));
     const int64_t ent = atom_entries > bond_entries ? atom_entries : bond_entries;
     y.emb_scratch = a.take(esc_bag_bwd_scratch(ent, H));
@@ -1112,8 +1233,8 @@ static int backward_ogb(const OgbCtx& z) {
       have_dhin = true;
     }
     ESC_TRY(esc_gine_aggregate_bwd(w.hin, H, w.e, H, y.dagg, H, b->out_ptr, b->out_edge, b->out_dst, q.eps, N, H, w.d_e, H,
-                                   dHin, H, have_dhin ? 1 : 0, y.deps_part + (int64_t)l * N, c.s));
-    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * N, N, q.deps});
+                                   dHin, H, have_dhin ? 1 : 0, y.deps_part + (int64_t)l * 2 * N, c.s));
+    eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * 2 * N, N * esc_gine_aggregate_bwd_deps_slots(H), q.deps});
     // edge term: bond tables and edge_encoder_pos — edge stream
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));
     // bond tables: on the edge stream — except for the LAST layer processed (l == 0), whose edge-term backward opens the tail of

@@ -88,6 +88,8 @@ struct GArgs {
   int c_vec;                         // set by the launcher: 16-byte row stores are legal
   int ntile_m, ntile_n;              // set by the launcher
   unsigned long long* stamps;        // diagnostics (tools/gemm_lab): per workgroup clock readings, or null
+  BnbDev bnb;                        // PRO bit 2
+  BnStatDev bst;                     // PRO bit 3
 };
 
 __device__ __forceinline__ void stamp(unsigned long long* base, int slot) {
@@ -109,23 +111,33 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
 
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
 struct Cfg {
+  static constexpr int P = PRO & 3;                                     // operand prologue (see GArgs)
+  static constexpr bool BNB = (PRO & 4) != 0, BSTAT = (PRO & 8) != 0;
   static constexpr int NW = WM * WN, NWT = NW + LW, NTHR = NWT * 64, DW = LW > 0 ? LW : NW;
-  static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE_FLOATS = A_FLOATS + B_FLOATS;
+  static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, A2_FLOATS = BNB ? A_FLOATS : 0;   // A2: the BatchNorm input rows beside dOut
+  static constexpr int STAGE_FLOATS = A_FLOATS + A2_FLOATS + B_FLOATS;
   static constexpr int PA = A_FLOATS / 256, PB = B_FLOATS / 256;        // 1-KiB pieces per tile
-  static constexpr int PPWA = PA / DW, PPWB = PB / DW, PPW = PPWA + PPWB;
+  static constexpr int PPWA = PA / DW, PPWB = PB / DW, PPW = PPWA * (BNB ? 2 : 1) + PPWB;
   static constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
   static constexpr int OUT_LD = BN + 4, OUT_FLOATS = BM * OUT_LD;       // epilogue staging image [BM][BN+4]
   static constexpr int STAT_FLOATS = STATS ? WM * BN * 3 : 0;           // (n, mean, M2) per wave row and column
   static constexpr int RING_FLOATS = STAGES * STAGE_FLOATS > OUT_FLOATS + STAT_FLOATS ? STAGES * STAGE_FLOATS : OUT_FLOATS + STAT_FLOATS;
-  static constexpr int PRO_MAXK = 1280;
-  static constexpr bool PRO_A = PRO == 1 || PRO == 3;                   // per-k affine + ReLU on a KC A operand
+  static constexpr int PRO_MAXK = 1280, BNB_MAXK = 640;
+  static constexpr bool PRO_A = P == 1 || P == 3;                       // per-k affine + ReLU on a KC A operand
+  static constexpr bool BNB_KC = BNB && !A_RM;                          // KC A: mean | scale | mask scale | mask shift | k1 | invstd k2 per k,
+                                                                        // 6 arrays of the (padded) reduction length BEHIND the static part: bnb_lds_floats(R)
+  static constexpr int BST_FLOATS = BSTAT ? NTHR * 8 : 0;               // epilogue: one (s1, s2) float4 pair per thread, inside the dead ring
   static constexpr int PRO_FLOATS = PRO_A ? 2 * PRO_MAXK : 0;           // scale | shift of the whole reduction range
   static constexpr size_t LDS_BYTES = (size_t)(RING_FLOATS + PRO_FLOATS) * 4;
+  static constexpr int bnb_lds_floats(int R) { return BNB_KC ? 6 * (((R + BK - 1) / BK) * BK) : 0; }
+  static_assert(OUT_FLOATS + STAT_FLOATS + BST_FLOATS <= RING_FLOATS, "the epilogue's images must fit the ring they reuse");
   static constexpr int C4 = BN / 4;                                     // float4 per output row of the tile
   static_assert(PA % DW == 0 && PB % DW == 0, "pieces must split evenly over the DMA waves");
   static_assert(MT >= 1 && NT >= 1 && STAGES >= 2 && STAGES <= 4, "bad tile");
   static_assert(NTHR % C4 == 0, "a thread keeps one column quad through the epilogue");
-  static_assert(PRO == 0 || (PRO_A && !A_RM) || (PRO == 2 && B_RM), "prologue: per-k on a KC A, or per-column on an RM B");
+  static_assert(P == 0 || (PRO_A && !A_RM) || (P == 2 && B_RM), "prologue: per-k on a KC A, or per-column on an RM B");
+  static_assert(!(BNB && PRO_A), "the BatchNorm backward and the affine prologue both transform A");
+  static_assert(!BSTAT || (!A_RM && B_RM && !STATS), "BatchNorm-backward partials ride on the input-gradient tiles");
   static_assert(!DB || A_RM, "bias gradient = column sums of a reduction-major A");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
 };
@@ -166,6 +178,8 @@ template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM,
 __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ lds, int wg) {
   using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
   constexpr int NW = C_::NW, DW = C_::DW;
+  constexpr int P = C_::P;
+  constexpr bool BNB = C_::BNB, BSTAT = C_::BSTAT;
   constexpr int PPWA = C_::PPWA, PPWB = C_::PPWB, PPW = C_::PPW;
   constexpr int TM = C_::TM, TN = C_::TN, MT = C_::MT, NT = C_::NT;
   constexpr int RB = BK * 4;
@@ -190,14 +204,26 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   int voa[PPWA], vob[PPWB], kca[PPWA], kcb[PPWB];
   dma_offsets<BM, BK, DW, PPWA, A_RM>(voa, kca, dw, l, m0, red0, g.lda);
   dma_offsets<BN, BK, DW, PPWB, B_RM>(vob, kcb, dw, l, n0, red0, g.ldb);
+  // BNB: the BatchNorm's input rows travel beside dOut — same tile, own base / leading dimension, image right behind A's.
+  // (Fetching them from global memory into registers in the fragment layout instead, one K-step ahead, keeps the ring at
+  // two images and three stages but measured SLOWER than this: the fragment-shaped loads are 32-byte pieces of 32 rows.)
+  i32x4 ra2 = ra;
+  int voa2[BNB ? PPWA : 1], kca2[BNB ? PPWA : 1];
+  if constexpr (BNB) {
+    ra2 = A_RM ? make_rsrc(g.bnb.x, (unsigned)(((size_t)(red1 - 1) * g.bnb.ldx + g.M) * 4))
+               : make_rsrc(g.bnb.x, (unsigned)(((size_t)(g.M - 1) * g.bnb.ldx + g.R) * 4));
+    dma_offsets<BM, BK, DW, PPWA, A_RM>(voa2, kca2, dw, l, m0, red0, g.bnb.ldx);
+  }
+
   constexpr int OOB = 0x7FFFFFF0;                           // beyond every descriptor's num_records: the load returns 0
   const int stepa = A_RM ? BK * g.lda * 4 : 0, stepb = B_RM ? BK * g.ldb * 4 : 0;   // RM: K-step inside the checked offset
+  const int stepa2 = (BNB && A_RM) ? BK * g.bnb.ldx * 4 : 0;
 
   const unsigned lds_base = lds_addr(lds);
   int issued = 0;                                           // K-steps issued so far by this wave
   auto stage = [&](int buf) {
     const unsigned a_dst = lds_base + (unsigned)(buf * C_::STAGE_FLOATS + dw * 256) * 4u;
-    const unsigned b_dst = a_dst + C_::A_FLOATS * 4u;
+    const unsigned b_dst = a_dst + (C_::A_FLOATS + C_::A2_FLOATS) * 4u;
     const int k0 = red0 + issued * BK;                      // first reduction index of this K-step
     const int soff = k0 * 4;                                // KC operands: K offset (an SGPR offset is not range-checked)
     const bool tail = k0 + BK > red1;                       // wave-uniform: the partial last K-step of a KC operand
@@ -207,6 +233,15 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
       if constexpr (!A_RM) { if (tail && k0 + kca[j] >= red1) vo = OOB; }
       dma16(ra, a_dst + (unsigned)(DW * j) * 1024u, vo, A_RM ? 0 : soff);
       if constexpr (A_RM) voa[j] += stepa;
+    }
+    if constexpr (BNB) {
+#pragma unroll
+      for (int j = 0; j < PPWA; ++j) {
+        int vo = voa2[j];
+        if constexpr (!A_RM) { if (tail && k0 + kca2[j] >= red1) vo = OOB; }
+        dma16(ra2, a_dst + C_::A_FLOATS * 4u + (unsigned)(DW * j) * 1024u, vo, A_RM ? 0 : soff);
+        if constexpr (A_RM) voa2[j] += stepa2;
+      }
     }
 #pragma unroll
     for (int j = 0; j < PPWB; ++j) {
@@ -233,7 +268,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   }
 
   float* pro = lds + C_::RING_FLOATS;     // PRO 1 / 3: [scale R | shift R]
-  if constexpr (PRO == 3) {               // merge the producer's BatchNorm partials here (see common.h); tile 0 keeps the results
+  if constexpr (P == 3) {                 // merge the producer's BatchNorm partials here (see common.h); tile 0 keeps the results
     for (int k = threadIdx.x; k < g.R; k += C_::NTHR) {
       float sc, sh;
       bn_fold_column(g.fold, k, wg == 0, sc, sh);
@@ -242,14 +277,51 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
     for (int k = g.R + threadIdx.x; k < ((g.R + BK - 1) / BK) * BK; k += C_::NTHR) { pro[k] = 0.f; pro[C_::PRO_MAXK + k] = 0.f; }   // partial last K-step: relu(0*0+0) = 0
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
-  if constexpr (PRO == 1) {
+  if constexpr (P == 1) {
     for (int k = threadIdx.x; k < g.R; k += C_::NTHR) { pro[k] = g.pro_scale[k]; pro[C_::PRO_MAXK + k] = g.pro_shift[k]; }
     for (int k = g.R + threadIdx.x; k < ((g.R + BK - 1) / BK) * BK; k += C_::NTHR) { pro[k] = 0.f; pro[C_::PRO_MAXK + k] = 0.f; }   // partial last K-step
     // the raw s_barrier of the first K-step publishes these writes: they must have LANDED before this wave arrives there
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
+  // BNB on a KC A (input-gradient tiles): six per-k arrays over the whole reduction range; k >= R: scale 0 -> operand 0
+  float* bnbc = lds + C_::RING_FLOATS + C_::PRO_FLOATS;
+  const int bnb_s = ((g.R + BK - 1) / BK) * BK;              // stride of the six coefficient arrays
+  if constexpr (BNB && !A_RM) {
+    const int S = bnb_s;
+    const int rpad = bnb_s;
+    // with loader waves the compute waves stage the coefficients: their vmcnt holds no DMA, so the wait below does not drain
+    // the ring's prologue transfers
+    const int kstart = LW > 0 ? (loader ? rpad : (int)threadIdx.x) : (int)threadIdx.x;
+    for (int k = kstart; k < rpad; k += (LW > 0 ? NW * 64 : C_::NTHR)) {
+      const bool in = k < g.R;
+      const float sc = in ? g.bnb.scale[k] : 0.f;
+      const float2 kk = in ? g.bnb.coef[k] : make_float2(0.f, 0.f);
+      bnbc[k] = in ? g.bnb.mean[k] : 0.f;
+      bnbc[S + k] = sc;
+      bnbc[2 * S + k] = g.bnb.relu ? sc : 0.f;                           // mask: fmaf(x, msc, msh) > 0 (no activation: always)
+      bnbc[3 * S + k] = g.bnb.relu ? (in ? g.bnb.shift[k] : 0.f) : 1.f;
+      bnbc[4 * S + k] = kk.x;
+      bnbc[5 * S + k] = in ? g.bnb.invstd[k] * kk.y : 0.f;
+    }
+    if (LW == 0 || !loader) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // published by the first K-step's raw s_barrier
+  }
+  // BNB on an RM A (weight-gradient tiles): the channel is the lane's column of every 32-column block
+  float q_mu[BNB && A_RM ? MT : 1], q_a[BNB && A_RM ? MT : 1], q_ms[BNB && A_RM ? MT : 1], q_mh[BNB && A_RM ? MT : 1],
+        q_k1[BNB && A_RM ? MT : 1], q_k2[BNB && A_RM ? MT : 1];
+  if constexpr (BNB && A_RM) {
+    auto load = [&](int col, float& mu, float& a, float& ms, float& mh, float& k1, float& k2) {
+      const bool in = col < g.M;
+      const float sc = in ? g.bnb.scale[col] : 0.f;
+      const float2 kk = in ? g.bnb.coef[col] : make_float2(0.f, 0.f);
+      mu = in ? g.bnb.mean[col] : 0.f; a = sc;
+      ms = g.bnb.relu ? sc : 0.f; mh = g.bnb.relu ? (in ? g.bnb.shift[col] : 0.f) : 1.f;
+      k1 = kk.x; k2 = in ? g.bnb.invstd[col] * kk.y : 0.f;
+    };
+#pragma unroll
+    for (int i = 0; i < MT; ++i) load(m0 + wm * TM + i * 32 + lr, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]);
+  }
   float cs[NT], ch_[NT];                  // PRO 2: this lane's column coefficients (column = lane & 31 of each block)
-  if constexpr (PRO == 2) {
+  if constexpr (P == 2) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + wn * TN + j * 32 + lr;
@@ -266,6 +338,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float dbsum = 0.f;
+  float dbfrag[(BNB && A_RM && DB) ? MT : 1] = {};          // BNB: per-lane column sums of the transformed A fragments
 
   // fragment addressing.  KC: row (lane & 31) of a 32-row block, logical chunk 2 c8 + h -> physical (2 c8) ^ y.
   // RM: reduction row 8 c8 + 4 h + t, column (lane & 31) of a 32-column block.
@@ -275,25 +348,41 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
 
   auto compute = [&](int buf, int kt) {
     const char* a_l = reinterpret_cast<const char*>(lds + buf * C_::STAGE_FLOATS);
-    const char* b_l = a_l + C_::A_FLOATS * 4;
-    if constexpr (DB) {     // column sums of the reduction-major A tile (bias gradient): first column tile only
+    const char* a2_l = a_l + C_::A_FLOATS * 4;
+    const char* b_l = a_l + (C_::A_FLOATS + C_::A2_FLOATS) * 4;
+    const int kstep0 = red0 + kt * BK;                                   // first reduction index of this K-step
+    if constexpr (DB && !BNB) {     // column sums of the reduction-major A tile (bias gradient): first column tile only
       if (n0 == 0 && (int)threadIdx.x < BM) {
         const float* col = reinterpret_cast<const float*>(a_l) + threadIdx.x;
 #pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) dbsum += col[kk * BM];
       }
     }
+    // (DB && BNB: the transformed fragments are summed where they are made — see transform)
     float4 af[2][MT], bf[2][NT], s4[2], h4[2];
+    float4 xf[2][BNB ? MT : 1], b6[2][(BNB && !A_RM) ? 6 : 1];          // BNB: the BatchNorm input fragments; KC A: per-k coefficients
+    int cq[2] = {0, 0};                                                  // the 8-chunk each fragment slot holds
     auto frags = [&](int c8, int q) {
       const int ch = (c8 << 5) ^ y16;
+      cq[q] = c8;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if constexpr (!A_RM) {
           af[q][i] = *reinterpret_cast<const float4*>(a_l + a_base + i * 32 * RB + ch);
+          if constexpr (BNB) xf[q][i] = *reinterpret_cast<const float4*>(a2_l + a_base + i * 32 * RB + ch);
         } else {
           const float* p = reinterpret_cast<const float*>(a_l + a_base + (c8 * 8 * BM + i * 32) * 4);
           af[q][i] = make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+          if constexpr (BNB) {
+            const float* px = reinterpret_cast<const float*>(a2_l + a_base + (c8 * 8 * BM + i * 32) * 4);
+            xf[q][i] = make_float4(px[0], px[BM], px[2 * BM], px[3 * BM]);
+          }
         }
+      }
+      if constexpr (BNB && !A_RM) {
+        const int k = kstep0 + c8 * 8 + h * 4;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) b6[q][u] = *reinterpret_cast<const float4*>(bnbc + u * bnb_s + k);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -310,8 +399,8 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
         h4[q] = *reinterpret_cast<const float4*>(pro + C_::PRO_MAXK + k);
       }
     };
-    constexpr int NREADS = (A_RM ? 4 : 1) * MT + (B_RM ? 4 : 1) * NT + (C_::PRO_A ? 2 : 0);
-    constexpr int NVALU = C_::PRO_A ? 8 * MT : (PRO == 2 ? 8 * NT : 0);
+    constexpr int NREADS = (A_RM ? 4 : 1) * MT * (BNB ? 2 : 1) + (B_RM ? 4 : 1) * NT + (C_::PRO_A ? 2 : 0) + ((BNB && !A_RM) ? 6 : 0);
+    constexpr int NVALU = (C_::PRO_A ? 8 * MT : (P == 2 ? 8 * NT : 0)) + (BNB ? 28 * MT : 0);
     constexpr int NMFMA = 4 * MT * NT;
     auto transform = [&](int q) {         // consumer-side BatchNorm + ReLU on the staged operand
       if constexpr (C_::PRO_A) {
@@ -322,7 +411,31 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
           v.z = fmaxf(fmaf(v.z, s4[q].z, h4[q].z), 0.f); v.w = fmaxf(fmaf(v.w, s4[q].w, h4[q].w), 0.f);
         }
       }
-      if constexpr (PRO == 2) {
+      if constexpr (BNB && !A_RM) {       // BatchNorm backward on the staged gradient: per-k coefficients
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float4& v = af[q][i];
+          const float4 x = xf[q][i];
+          v.x = bnb_apply(v.x, x.x, b6[q][0].x, b6[q][1].x, b6[q][2].x, b6[q][3].x, b6[q][4].x, b6[q][5].x);
+          v.y = bnb_apply(v.y, x.y, b6[q][0].y, b6[q][1].y, b6[q][2].y, b6[q][3].y, b6[q][4].y, b6[q][5].y);
+          v.z = bnb_apply(v.z, x.z, b6[q][0].z, b6[q][1].z, b6[q][2].z, b6[q][3].z, b6[q][4].z, b6[q][5].z);
+          v.w = bnb_apply(v.w, x.w, b6[q][0].w, b6[q][1].w, b6[q][2].w, b6[q][3].w, b6[q][4].w, b6[q][5].w);
+        }
+      }
+      if constexpr (BNB && A_RM) {        // ... per-column coefficients; reduction rows past the split's end contribute nothing
+        const int r0 = kstep0 + cq[q] * 8 + h * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float4& v = af[q][i];
+          const float4 x = xf[q][i];
+          v.x = r0 + 0 < red1 ? bnb_apply(v.x, x.x, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
+          v.y = r0 + 1 < red1 ? bnb_apply(v.y, x.y, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
+          v.z = r0 + 2 < red1 ? bnb_apply(v.z, x.z, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
+          v.w = r0 + 3 < red1 ? bnb_apply(v.w, x.w, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
+          if constexpr (DB) dbfrag[i] += (v.x + v.y) + (v.z + v.w);      // bias gradient: this lane's share of its column's sum
+        }
+      }
+      if constexpr (P == 2) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float4& v = bf[q][j];
@@ -440,9 +553,19 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
       }
     }
   }
-  if constexpr (DB) {
+  if constexpr (DB && !BNB) {
     if (n0 == 0 && (int)threadIdx.x < BM && m0 + (int)threadIdx.x < g.M)
       g.db_part[(size_t)split * g.M + m0 + threadIdx.x] = dbsum;
+  }
+  if constexpr (DB && BNB) {      // the two lane halves hold the k = 4h.. shares of the same column; wave column 0 of every wave row writes
+    if (n0 == 0 && !loader && wn == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float tsum = dbfrag[i] + __shfl_xor(dbfrag[i], 32, 64);
+        const int col = m0 + wm * TM + i * 32 + lr;
+        if (h == 0 && col < g.M) g.db_part[(size_t)split * g.M + col] = tsum;
+      }
+    }
   }
   // ---- epilogue: the tile is staged through LDS (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h) and
   // leaves as whole rows, 16 bytes per lane
@@ -493,6 +616,25 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
     const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
     const int col = n0 + c4 * 4;
     float* Cb = g.C + (size_t)split * g.M * g.ldc;           // split > 0 only for slab outputs
+    // BSTAT: C is the gradient of a BatchNorm(+ReLU) output; every thread sums (g, g*xhat) of its column quad over the rows
+    // it stores, the workgroup adds the per-thread sums in row order and writes ONE partial per tile row block and column
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1, e_mu = t1, e_is = t1, e_ms = t1, e_mh = make_float4(1.f, 1.f, 1.f, 1.f);
+    bool bstat = false;
+    float4 ypre[BSTAT ? ITERS : 1];                          // the BatchNorm input rows of this thread's quads, fetched up front
+    if constexpr (BSTAT) {
+      bstat = g.bst.partial != nullptr && g.c_vec;           // workgroup-uniform
+      if (bstat && col < g.N) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int row = m0 + rr + it * RPI;
+          ypre[it] = (row < g.M && (BM % RPI == 0 || rr + it * RPI < BM)) ? *reinterpret_cast<const float4*>(g.bst.x + (size_t)row * g.bst.ldx + col)
+                                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        e_mu = *reinterpret_cast<const float4*>(g.bst.mean + col);
+        e_is = *reinterpret_cast<const float4*>(g.bst.invstd + col);
+        if (g.bst.relu) { e_ms = *reinterpret_cast<const float4*>(g.bst.scale + col); e_mh = *reinterpret_cast<const float4*>(g.bst.shift + col); }
+      }
+    }
     if (g.c_vec) {
       if (col < g.N) {                                       // N % 4 == 0: whole quads only
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -508,6 +650,34 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
             float4* dst = reinterpret_cast<float4*>(cp + it * step);
             if (g.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             *dst = v;
+            if constexpr (BSTAT) {
+              if (bstat) {
+                const float4 y = ypre[it];
+                const float gx = fmaf(y.x, e_ms.x, e_mh.x) > 0.f ? v.x : 0.f, gy = fmaf(y.y, e_ms.y, e_mh.y) > 0.f ? v.y : 0.f;
+                const float gz = fmaf(y.z, e_ms.z, e_mh.z) > 0.f ? v.z : 0.f, gw = fmaf(y.w, e_ms.w, e_mh.w) > 0.f ? v.w : 0.f;
+                t1.x += gx; t1.y += gy; t1.z += gz; t1.w += gw;
+                t2.x = fmaf(gx, (y.x - e_mu.x) * e_is.x, t2.x); t2.y = fmaf(gy, (y.y - e_mu.y) * e_is.y, t2.y);
+                t2.z = fmaf(gz, (y.z - e_mu.z) * e_is.z, t2.z); t2.w = fmaf(gw, (y.w - e_mu.w) * e_is.w, t2.w);
+              }
+            }
+          }
+        }
+      }
+      if constexpr (BSTAT) {
+        if (bstat) {
+          float4* red = reinterpret_cast<float4*>(lds + C_::OUT_FLOATS + C_::STAT_FLOATS);   // (behind the output image, inside the dead ring)
+          red[threadIdx.x * 2] = t1; red[threadIdx.x * 2 + 1] = t2;
+          __syncthreads();
+          if (rr == 0 && col < g.N) {
+#pragma unroll 4
+            for (int r = 1; r < RPI; ++r) {
+              const float4 u1 = red[(r * C4 + c4) * 2], u2 = red[(r * C4 + c4) * 2 + 1];
+              t1.x += u1.x; t1.y += u1.y; t1.z += u1.z; t1.w += u1.w;
+              t2.x += u2.x; t2.y += u2.y; t2.z += u2.z; t2.w += u2.w;
+            }
+            float2* dstp = g.bst.partial + (size_t)(m0 / BM) * g.N + col;
+            *reinterpret_cast<float4*>(dstp) = make_float4(t1.x, t2.x, t1.y, t2.y);
+            *reinterpret_cast<float4*>(dstp + 2) = make_float4(t1.z, t2.z, t1.w, t2.w);
           }
         }
       }
@@ -543,13 +713,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_kernel(GArgs g) {
 // (TN).  Both stream the same dY; one launch instead of two removes a boundary and lets the two under-filled grids
 // of the node-sized layers share the chip.
 struct DualArgs { GArgs dx, dw; int n_dx; };
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
+// BNB: dY is still the gradient of the BatchNorm(+ReLU) OUTPUT; its backward is applied to the operand as it is staged
+// (both jobs); BSTAT: the dX tiles also emit the column sums of the NEXT BatchNorm backward (see BnbDev / BnStatDev).
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO, bool BNB = false, bool BSTAT = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_dual_kernel(DualArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if constexpr (BM * BN < 128 * 128) ESC_PRIO();
   const int b = (int)blockIdx.x;
-  if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>(a.dx, lds, b);
-  else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>(a.dw, lds, b - a.n_dx);
+  if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, (BNB ? 4 : 0) | (BSTAT ? 8 : 0), false, false>(a.dx, lds, b);
+  else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, (PRO ? 2 : 0) | (BNB ? 4 : 0), false, true>(a.dw, lds, b - a.n_dx);
 }
 
 inline int splits_of(const GArgs& g) { return g.red_per_split >= g.R ? 1 : (int)cdiv(g.R, g.red_per_split); }
@@ -586,12 +758,13 @@ inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind
   return hipSuccess;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO, bool BNB = false, bool BSTAT = false>
 inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
-  using CX = Cfg<BM, BN, BK, WM, WN, STAGES, LW, false, true, 0, false, false>;
-  using CW = Cfg<BM, BN, BK, WM, WN, STAGES, LW, true, true, PRO ? 2 : 0, false, true>;
-  auto kern = gemm_dual_kernel<BM, BN, BK, WM, WN, STAGES, LW, PRO>;
-  size_t lds = CX::LDS_BYTES > CW::LDS_BYTES ? CX::LDS_BYTES : CW::LDS_BYTES;
+  using CX = Cfg<BM, BN, BK, WM, WN, STAGES, LW, false, true, (BNB ? 4 : 0) | (BSTAT ? 8 : 0), false, false>;
+  using CW = Cfg<BM, BN, BK, WM, WN, STAGES, LW, true, true, (PRO ? 2 : 0) | (BNB ? 4 : 0), false, true>;
+  auto kern = gemm_dual_kernel<BM, BN, BK, WM, WN, STAGES, LW, PRO, BNB, BSTAT>;
+  const size_t lds_x = CX::LDS_BYTES + (size_t)CX::bnb_lds_floats(a.dx.R) * 4;        // (+ the dX job's per-k BatchNorm coefficients)
+  size_t lds = lds_x > CW::LDS_BYTES ? lds_x : CW::LDS_BYTES;
   if (lds_floor > lds) lds = lds_floor;
   static size_t raised_to = 64 * 1024;
   hipError_t e = raise_lds(kern, lds, raised_to);

@@ -980,14 +980,15 @@ static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, 
                     const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y, float* col_stats,
                     hipStream_t s, int* rc) {
   if (!(g_use_dma & 1) || K % 4 != 0 || K < 32 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && cdiv(K, 32) * 32 > 1280)) return false;
-  if (N <= 32 && (!(g_use_dma & 8) || col_stats != nullptr || in_scale != nullptr)) return false;
+  if (N <= 32 && (!(g_use_dma & 8) || col_stats != nullptr)) return false;
   dma::GArgs g{};
   g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.col_stats = reinterpret_cast<float2*>(col_stats);
   g.M = (int)M; g.N = (int)N; g.R = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
   hipError_t e;
   if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
-    e = dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
+    e = in_scale ? dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 1, false, false>(g, 0, s)
+                 : dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
   } else if (dma_big(M, N)) {             // edge-sized (or enough 128-row tiles to fill the chip): 128x128 tile, 4 compute + 4 loader waves
     if (in_scale)               e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s);
     else if (tile128_ok(N))     e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
@@ -1205,7 +1206,7 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
     static size_t raised_to = 64 * 1024;
     if (dma_check(dma::raise_lds(small::smalln_dx<small::SMALL_MAX>, lds, raised_to), "esc_linear_bwd_input") != hipSuccess) return ESC_ELAUNCH;
     esc::launch(ESC_K_LINEAR, small::smalln_dx<small::SMALL_MAX>, dim3((unsigned)cdiv(M, 32)), dim3(256), lds, s, dY, ld_dy, W, ld_w,
-                (int)M, (int)N, (int)K, dX, ld_dx, accumulate);
+                (int)M, (int)N, (int)K, dX, ld_dx, accumulate, BnbDev{});
     ESC_CHECK_LAUNCH("esc_linear_bwd_input.smalln");
     return ESC_OK;
   }
@@ -1288,7 +1289,7 @@ static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t l
     float* db_part = slabs + (size_t)splits * N * K;
     const bool small_k = K <= small::SMALL_MAX;
     const dim3 grid((unsigned)splits, (unsigned)cdiv(small_k ? N : K, 256));
-#define ESC_WGRAD_SMALL(SK, PR) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, SK, PR>, grid, dim3(256), 0, s, dY, ld_dy, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part)
+#define ESC_WGRAD_SMALL(SK, PR) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, SK, PR>, grid, dim3(256), 0, s, dY, ld_dy, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, BnbDev{})
     if (small_k) { if (in_scale) ESC_WGRAD_SMALL(true, true); else ESC_WGRAD_SMALL(true, false); }
     else         { if (in_scale) ESC_WGRAD_SMALL(false, true); else ESC_WGRAD_SMALL(false, false); }
 #undef ESC_WGRAD_SMALL
@@ -1494,6 +1495,93 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
   esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
               splits, (int)K, dW, ld_dw, w.db_part, (int)N, db);
   ESC_CHECK_LAUNCH("esc_linear_bwd_both.reduce");
+  return ESC_OK;
+}
+
+
+// ---- Linear backward with the BatchNorm(+ReLU) backward of its dY folded in (include/escgnn_hip.h, r03) ----------------
+static inline BnbDev bnb_dev(const esc_bn_bwd_fused* b) {
+  return BnbDev{b->x, (int)b->ld_x, b->mean, b->invstd, b->scale, b->shift, reinterpret_cast<const float2*>(b->coef), b->relu ? 1 : 0};
+}
+static inline bool bnb_operands_ok(const esc_bn_bwd_fused* b, int64_t M, int64_t N) {
+  return b && b->x && b->mean && b->invstd && b->scale && b->shift && b->coef && (b->relu == 0 || b->relu == 1) && b->ld_x >= N &&
+         dma_ok(b->x, M, b->ld_x) && aligned16(b->mean) && aligned16(b->invstd) && aligned16(b->scale) && aligned16(b->shift) &&
+         aligned16(b->coef);
+}
+static inline bool bnb_small_shape(int64_t N, int64_t K) { return (g_use_dma & 4) && K <= small::SMALL_MAX && N > small::SMALL_MAX && N % 4 == 0 && N <= 1024; }
+
+int esc_linear_bwd_both_bn_ok(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
+                              const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx,
+                              const float* slabs, const esc_bn_bwd_next* next) {
+  if (!dOut || !X || !W || !slabs || M <= 1 || M >= 8192 || N <= 0 || K <= 0 || (bn == nullptr && next == nullptr)) return 0;
+  if (bn != nullptr && !bnb_operands_ok(bn, M, N)) return 0;
+  if (bn != nullptr && bnb_small_shape(N, K))
+    return next == nullptr && aligned16(dOut) && ld_dout % 4 == 0 && ld_dout >= N && ld_x >= K && ld_w >= K && (dX == nullptr || ld_dx >= K);
+  if (dX == nullptr || N > dma::Cfg<64, 64, 32, 2, 2, 2, 2, false, true, 4, false, false>::BNB_MAXK) return 0;
+  if (!dma_bwd_ok(dOut, ld_dout, X, ld_x, W, ld_w, M, N, K, dX, ld_dx, slabs, true, true)) return 0;
+  if (next) {
+    if (!next->partial || !next->x || !next->mean || !next->invstd || !next->scale || !next->shift || next->ld_x < K || next->ld_x % 4 != 0 ||
+        !aligned16(next->x) || !aligned16(next->mean) || !aligned16(next->invstd) || !aligned16(next->scale) || !aligned16(next->shift) ||
+        !aligned16(next->partial) || K % 4 != 0 || ld_dx % 4 != 0 || !aligned16(dX) || (next->relu != 0 && next->relu != 1))
+      return 0;
+  }
+  return 1;
+}
+
+int64_t esc_linear_bwd_bn_block_rows(int64_t M, int64_t N, int64_t K) { (void)M; (void)N; (void)K; return 64; }
+
+int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
+                           const float* in_scale, const float* in_shift, const float* W, int64_t ld_w, int64_t M,
+                           int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw,
+                           float* db, float* slabs, esc_reduce_job* defer, const esc_bn_bwd_next* next, void* stream) {
+  ESC_REQUIRE(dOut && X && W && dW && slabs, "esc_linear_bwd_both_bn: null pointer");
+  ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_bwd_both_bn: in_scale/in_shift must come together");
+  ESC_REQUIRE(ld_dw >= K, "esc_linear_bwd_both_bn: bad sizes");
+  ESC_REQUIRE(esc_linear_bwd_both_bn_ok(dOut, ld_dout, bn, X, ld_x, W, ld_w, M, N, K, dX, ld_dx, slabs, next),
+              "esc_linear_bwd_both_bn: shape / alignment not served (M=%ld N=%ld K=%ld) - use esc_bn_bwd + esc_linear_bwd_both", (long)M, (long)N, (long)K);
+  hipStream_t s = (hipStream_t)stream;
+  const BnbDev bd = bn ? bnb_dev(bn) : BnbDev{};
+  const int64_t n = N * K;
+  if (bn && bnb_small_shape(N, K)) {                       // in_dim-wide Linear (x_embedding.0, conv1.nn.0): see linear_small.h
+    const int splits = (int)cdiv(M, small::ROWS_WGRAD);
+    float* db_part = slabs + (size_t)splits * N * K;
+    const dim3 grid((unsigned)splits, (unsigned)cdiv(N, 256));
+    if (in_scale) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, true, true, true>, grid, dim3(256), 0, s, dOut, ld_dout, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, bd);
+    else          esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, true, false, true>, grid, dim3(256), 0, s, dOut, ld_dout, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, bd);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_both_bn.small");
+    if (dX != nullptr) {
+      const size_t lds = (size_t)(32 + small::SMALL_MAX) * (N + 4) * sizeof(float);
+      static size_t raised_to = 64 * 1024;
+      auto kern = small::smalln_dx<small::SMALL_MAX, true>;
+      if (dma_check(dma::raise_lds(kern, lds, raised_to), "esc_linear_bwd_both_bn") != hipSuccess) return ESC_ELAUNCH;
+      esc::launch(ESC_K_LINEAR, kern, dim3((unsigned)cdiv(M, 32)), dim3(256), lds, s, dOut, ld_dout, W, ld_w, (int)M, (int)N, (int)K, dX, ld_dx, accumulate, bd);
+      ESC_CHECK_LAUNCH("esc_linear_bwd_both_bn.smalln");
+    }
+    if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, db_part, N, db); return ESC_OK; }
+    esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+                splits, (int)K, dW, ld_dw, db_part, (int)N, db);
+    ESC_CHECK_LAUNCH("esc_linear_bwd_both_bn.reduce");
+    return ESC_OK;
+  }
+  int splits, per;
+  dma_wgrad_plan(M, N, K, 64, 64, &splits, &per);
+  dma::DualArgs a{};
+  dma_fill_dx(a.dx, dOut, ld_dout, W, ld_w, M, N, K, dX, ld_dx, accumulate);
+  dma_fill_dw(a.dw, dOut, ld_dout, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
+  a.dx.bnb = bd; a.dw.bnb = bd;
+  if (next)
+    a.dx.bst = BnStatDev{reinterpret_cast<float2*>(next->partial), next->x, (int)next->ld_x, next->mean, next->invstd, next->scale, next->shift, next->relu ? 1 : 0};
+  hipError_t e;
+  // (the third operand image of the fused apply costs a ring stage: two stages keep the workgroup at 54 KB, which fits beside
+  // an edge-stream GEMM on a CU; three stages — 78 KB — measured slower inside the two-stream step)
+  if (bn == nullptr) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true, false, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false, false, true>(a, 0, s);
+  else if (next) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, true>(a, 0, s);
+  else      e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, false>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, false>(a, 0, s);
+  if (dma_check(e, "esc_linear_bwd_both_bn") != hipSuccess) return ESC_ELAUNCH;
+  if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, a.dw.db_part, N, db); return ESC_OK; }
+  esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,
+              splits, (int)K, dW, ld_dw, a.dw.db_part, (int)N, db);
+  ESC_CHECK_LAUNCH("esc_linear_bwd_both_bn.reduce");
   return ESC_OK;
 }
 

@@ -1089,6 +1089,24 @@ int esc_bn_bwd_sums(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, 
                        (float2*)scratch, (float2*)sums, (hipStream_t)stream);
 }
 
+int esc_bn_bwd_coef(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY, int64_t ld_dy, int64_t M,
+                    int64_t C, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                    float* coef, float* dgamma, float* dbeta, float* scratch, void* stream) {
+  ESC_REQUIRE(X && dY && coef && mean && invstd && scratch, "esc_bn_bwd_coef: null pointer");
+  ESC_REQUIRE(M > 0 && C > 0 && ld_x >= C && ld_dy >= C && (!Y || ld_y >= C) && M < (1LL << 31), "esc_bn_bwd_coef: bad sizes");
+  return bn_bwd_reduce(X, ld_x, Y, ld_y, dY, ld_dy, M, C, mean, invstd, gamma, beta, relu, M, true, dgamma, dbeta,
+                       (float2*)scratch, (float2*)coef, (hipStream_t)stream);
+}
+
+int esc_bn_bwd_coef_from_partials(const float* partial, int64_t slots, int64_t M, int64_t C, float* coef, float* dgamma,
+                                  float* dbeta, void* stream) {
+  ESC_REQUIRE(partial && coef && slots > 0 && M > 0 && C > 0 && M < (1LL << 31) && slots < (1LL << 31), "esc_bn_bwd_coef_from_partials: bad arguments");
+  esc::launch(ESC_K_NORM, bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream,
+              reinterpret_cast<const float2*>(partial), (int)M, (int)C, (int)slots, dgamma, dbeta, reinterpret_cast<float2*>(coef));
+  ESC_CHECK_LAUNCH("esc_bn_bwd_coef_from_partials");
+  return ESC_OK;
+}
+
 int esc_bn_bwd_apply(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY,
                      int64_t ld_dy, int64_t M, int64_t C, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, int relu, const float* coef, float* dX,

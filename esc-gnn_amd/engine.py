@@ -127,9 +127,32 @@ def engine_supports(m):
         return False
     if m.lin2.out_features != 1 or m.lin2.in_features % 4 != 0:
         return False
+    return _one_sync_group(m)
+
+
+def _one_sync_group(m):
+    """no SyncBN at all, or EVERY BatchNorm of the model on the same process group (the engines exchange all statistics
+    through one collective provider)"""
     groups = _sync_groups(m)
     n_bn = sum(1 for mod in m.modules() if hasattr(mod, "sync_group"))
     return not groups or (len(groups) == n_bn and all(g is groups[0] for g in groups))
+
+
+def _bn_width(m):
+    """widest BatchNorm of the model (the exchange buffers hold world * 3 * width floats)"""
+    return max([mod.num_features for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)] or [1])
+
+
+def _arm_collective(model, device):
+    """SyncBN models: (re)install the engines' all-reduce for the model's group; others: nothing to do"""
+    groups = _sync_groups(model)
+    if not groups:
+        return
+    if not _one_sync_group(model):
+        raise NotImplementedError("step engine: all BatchNorm layers must share one sync group")
+    width = _bn_width(model)
+    if _collective.get("group", False) is not groups[0] or _collective.get("width", 0) < width:
+        install_collective(width, device, groups[0])
 
 
 _ALLREDUCE_T = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_int64, c_void_p, c_void_p)
@@ -166,7 +189,7 @@ def install_collective(hidden, device, group=None):
 
     cb = _ALLREDUCE_T(allreduce)
     nv.call("esc_engine_set_collective", ctypes.cast(cb, c_void_p), None, rank, world, bufs[0].data_ptr(), bufs[1].data_ptr(), cap)
-    _collective.update(cb=cb, bufs=bufs, group=group, world=world)
+    _collective.update(cb=cb, bufs=bufs, group=group, world=world, width=hidden)
     return True
 
 
@@ -216,11 +239,7 @@ class StepEngine(_AddressGuard):
             raise RuntimeError("StepEngine runs on the HIP device only; there is no CPU fallback")
         self.model = model
         self._ws = None
-        groups = _sync_groups(model)
-        if groups:                                           # SyncBN: the engine exchanges the statistics itself
-            if not engine_supports(model):
-                raise NotImplementedError("StepEngine: all BatchNorm layers must share one sync group")
-            install_collective(model.lin2.in_features, model.lin1.weight.device, groups[0])
+        _arm_collective(model, model.lin1.weight.device)     # SyncBN: the engine exchanges the statistics itself
         self._bn_counters = [m.num_batches_tracked for m in model.modules()
                              if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
         self.refresh()
@@ -427,9 +446,7 @@ def engine_predict(model, data):
 
 
 def engine_forward(model, data):
-    groups = _sync_groups(model)
-    if groups and _collective.get("group", False) is not groups[0]:      # SyncBN: the engine needs its all-reduce
-        install_collective(model.lin2.in_features, model.lin1.weight.device, groups[0])
+    _arm_collective(model, model.lin1.weight.device)         # SyncBN: the engine needs its all-reduce
     cache = _node_cache(model)
     return _EngineNode.apply(model, data, cache, *cache.params)
 
@@ -462,9 +479,10 @@ def describe_zinc(m, gp=_grad_ptr):
 
 
 def zinc_engine_supports(m, data=None):
-    """what esc_zinc_* covers: the run_zinc configuration (dropout 0, per-rank BatchNorm statistics), sparse ESC bag,
-    at least two graphs in the batch (the reference skips bn_lin1 for one, zinc_models.py:603-604)"""
-    if m.dropout != 0 or m.lin1.weight.device.type != "cuda" or m.lin2.out_features != 1 or _sync_groups(m):
+    """what esc_zinc_* covers: the run_zinc configuration (dropout 0; BatchNorm statistics per rank or, after
+    nn.BatchNorm1d.convert_sync, over ONE process group through the collective provider), sparse ESC bag, at least two graphs
+    in the batch (the reference skips bn_lin1 for one, zinc_models.py:603-604)"""
+    if m.dropout != 0 or m.lin1.weight.device.type != "cuda" or m.lin2.out_features != 1 or not _one_sync_group(m):
         return False
     if data is not None:
         if "edge_pos" in data or "pos_batch" not in data or data.edge_index.size(1) < 2 or data["edge_attr"] is None:
@@ -532,9 +550,10 @@ class ZincStepEngine(_AddressGuard):
 
     def __init__(self, model):
         if not zinc_engine_supports(model):
-            raise NotImplementedError("ZincStepEngine covers dropout 0, lin2 -> 1 output, per-rank BatchNorm on the HIP device")
+            raise NotImplementedError("ZincStepEngine covers dropout 0, lin2 -> 1 output, BatchNorm on one sync group, on the HIP device")
         self.model = model
         self._ws = None
+        _arm_collective(model, model.lin1.weight.device)
         self._bn_counters = [m.num_batches_tracked for m in model.modules()
                              if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
         self.refresh()
@@ -651,6 +670,7 @@ def zinc_engine_predict(model, data):
 
 
 def zinc_engine_forward(model, data):
+    _arm_collective(model, model.lin1.weight.device)
     c = model.__dict__.get("_esc_node_cache")
     if c is None or not c.valid():
         c = _ZincNodeCache(model)
@@ -693,10 +713,11 @@ class _OgbBatch(ctypes.Structure):
 
 def ogb_engine_supports(m, data=None):
     """what esc_ogb_* covers: the run_ogb_mol `--gnn gin_eff` configuration — ogbg-mol* encoders, virtual node, JK last,
-    sum / mean pooling, per-rank BatchNorm statistics; sparse ESC bag; at least two graphs per batch"""
+    sum / mean pooling, BatchNorm statistics per rank or over ONE process group (nn.BatchNorm1d.convert_sync); sparse ESC bag;
+    at least two graphs per batch"""
     from .ogb_mol_gnn import AtomEncoder, BondEncoder
     g = m.gnn_node
-    if g.JK != "last" or not g.virtual_node or g.skip_node_encoder or m.graph_pooling not in ("sum", "mean") or _sync_groups(m):
+    if g.JK != "last" or not g.virtual_node or g.skip_node_encoder or m.graph_pooling not in ("sum", "mean") or not _one_sync_group(m):
         return False
     if m.graph_pred_linear.weight.device.type != "cuda" or m.emb_dim % 4 != 0 or not isinstance(g.node_encoder, AtomEncoder):
         return False
@@ -821,6 +842,7 @@ class OgbStepEngine(_AddressGuard):
             raise NotImplementedError("OgbStepEngine covers ogbg-mol* gin_eff with a virtual node, JK=last, sum/mean pooling")
         self.model = model
         self._ws = None
+        _arm_collective(model, model.graph_pred_linear.weight.device)
         self._bn_counters = [m.num_batches_tracked for m in model.modules()
                              if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
         self.refresh()
@@ -929,6 +951,7 @@ def ogb_engine_predict(model, data):
 
 
 def ogb_engine_forward(model, data):
+    _arm_collective(model, model.graph_pred_linear.weight.device)
     c = model.__dict__.get("_esc_node_cache")
     if c is None or not c.valid():
         c = _OgbNodeCache(model)

@@ -110,14 +110,15 @@ class _GineAggregate(Function):
         need_dx, need_de, need_eps = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         d_e = torch.empty_like(e)
         dx = torch.empty((N, C), dtype=torch.float32, device=x.device) if need_dx else None
-        part = torch.empty(N, dtype=torch.float32, device=x.device) if need_eps else None
+        slots = int(nv.lib().esc_gine_aggregate_bwd_deps_slots(C))       # partial dot products per row (see the header)
+        part = torch.empty(N * slots, dtype=torch.float32, device=x.device) if need_eps else None
         nv.call("esc_gine_aggregate_bwd", nv.ptr(x), x.stride(0), nv.ptr(e), e.stride(0), nv.ptr(g), ldg,
                 nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, C,
                 nv.ptr(d_e), d_e.stride(0), nv.ptr(dx), C, 0, nv.ptr(part), nv.stream())
         deps = None
         if need_eps:
             deps = torch.empty(1, dtype=torch.float32, device=x.device)
-            nv.call("esc_reduce_sum", nv.ptr(part), N, nv.ptr(deps), nv.stream())
+            nv.call("esc_reduce_sum", nv.ptr(part), N * slots, nv.ptr(deps), nv.stream())
         return dx, (d_e if need_de else None), deps, None
 
 

@@ -76,7 +76,9 @@ int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t
                            void* stream);
 /* backward, CSR by source (out_ptr/out_edge/out_dst): d_e[k,:] = [x[src_k]+e_k > 0] * g[dst_k,:];
  * dx[i,:] = (1+eps)*g[i,:] + sum_{k in out(i)} d_e[k,:]  (dx may be NULL);
- * deps_part[i] = sum_c g[i,c]*x[i,c]  (deps_part may be NULL). */
+ * deps_part (may be NULL): per-row partial dot products sum_c g[i,c]*x[i,c] whose total is d(eps): N * S floats with
+ * S = esc_gine_aggregate_bwd_deps_slots(C) (1; 2 when rows of C floats are split over two waves, ESC_AGG_SPLIT_BWD=2). */
+int esc_gine_aggregate_bwd_deps_slots(int64_t C);
 int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t ld_e,
                            const float* g, int64_t ld_g, const int32_t* out_ptr,
                            const int32_t* out_edge, const int32_t* out_dst, const float* eps,
@@ -239,6 +241,55 @@ int esc_linear_bwd_both_deferred(const float* dY, int64_t ld_dy, const float* X,
                                  float* dW, int64_t ld_dw, float* db, float* slabs, esc_reduce_job* job,
                                  void* stream);
 int esc_slab_reduce_jobs(const esc_reduce_job* jobs /* host array */, int count, void* stream);
+
+/* ---- Linear backward with the BatchNorm(+ReLU) backward in front of it folded in (r03) ---------------------------
+ * Call sites: every `Linear -> BatchNorm1d -> ReLU` pair of the node-sized MLPs, run_graphcount.py:65-73 (x_embedding),
+ * :78-87 / :98-107 (GINEConv.nn) and :183-186 (lin1 -> bn_lin1).  Their backward used to be
+ *     bn_bwd partial -> finalize -> apply (writes dY) -> Linear backward (reads dY):
+ * four dependent launches of ~5 us each on the latency-bound node chain.  Here the APPLY step happens while the Linear
+ * backward stages its dY operand (and the PARTIAL sums of the next BatchNorm can ride in the dX epilogue), so only the
+ * finalize stays on the chain.
+ *   dOut       gradient of the BatchNorm(+ReLU) OUTPUT [M, N]
+ *   bn         its input rows, batch statistics, forward coefficients (scale = gamma*invstd, shift = beta - mean*scale, as
+ *              esc_bn_stats writes them) and coef = float2[N] (sum g, sum g*xhat) / M from esc_bn_bwd_coef[_from_partials];
+ *              relu in {0, 1} (the mask is recomputed as fmaf(x, scale, shift) > 0, the forward's own expression)
+ *   next       optional: dX is itself the gradient of a BatchNorm(+ReLU) output over K channels whose input rows are
+ *              next->x; the dX tiles then also write partial[row_block][K] = (sum g, sum g*xhat) of their rows
+ *              (row blocks of esc_linear_bwd_bn_block_rows(M, N, K) rows) for esc_bn_bwd_coef_from_partials.
+ * Result: dX / dW / db equal esc_bn_bwd_apply followed by esc_linear_bwd_both[_deferred] (same arithmetic per element;
+ * the operand is never written to memory).  job == NULL reduces the slabs at once.
+ * esc_linear_bwd_both_bn_ok tells whether a shape is served (node-sized rows, 16-byte aligned operands, N <= 640 on
+ * the MFMA tiles or K <= 16 on the narrow-input kernels); callers fall back to the unfused sequence otherwise.
+ * bn == NULL (with next != NULL): dOut is a plain dY — only the next BatchNorm's column sums are folded in. */
+typedef struct esc_bn_bwd_fused {
+  const float* x; int64_t ld_x;
+  const float* mean; const float* invstd; const float* scale; const float* shift;
+  const float* coef;
+  int32_t relu;
+} esc_bn_bwd_fused;
+typedef struct esc_bn_bwd_next {
+  float* partial;
+  const float* x; int64_t ld_x;
+  const float* mean; const float* invstd; const float* scale; const float* shift;
+  int32_t relu;
+} esc_bn_bwd_next;
+int esc_linear_bwd_both_bn_ok(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
+                              const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx,
+                              const float* slabs, const esc_bn_bwd_next* next);
+int64_t esc_linear_bwd_bn_block_rows(int64_t M, int64_t N, int64_t K);
+int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
+                           const float* in_scale, const float* in_shift, const float* W, int64_t ld_w, int64_t M,
+                           int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw,
+                           float* db, float* slabs, esc_reduce_job* job, const esc_bn_bwd_next* next, void* stream);
+/* coef[c] = (sum g, sum g*xhat) / M, dgamma, dbeta of a BatchNorm(+ReLU) backward — the first two of esc_bn_bwd's three
+ * steps (relu in {0, 1, 2}; Y as in esc_bn_bwd) ... */
+int esc_bn_bwd_coef(const float* X, int64_t ld_x, const float* Y, int64_t ld_y, const float* dY, int64_t ld_dy, int64_t M,
+                    int64_t C, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                    float* coef, float* dgamma, float* dbeta, float* scratch, void* stream);
+/* ... or only the second, from `slots` partial rows float2[slots][C] a producer left (esc_linear_bwd_both_bn's `next`,
+ * esc_gine_aggregate_bwd_stats): summed in slot order in fp64 */
+int esc_bn_bwd_coef_from_partials(const float* partial, int64_t slots, int64_t M, int64_t C, float* coef, float* dgamma,
+                                  float* dbeta, void* stream);
 
 /* ---- BatchNorm1d (training statistics) + ReLU, torch.nn.BatchNorm1d call sites
  * run_graphcount.py:55-60,66-72,80-87,115 --------------------------------------------------

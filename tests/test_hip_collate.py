@@ -185,6 +185,35 @@ def test_segment_pointers_beyond_the_radix_key_range(E):
         _csr(key.to(DEV), n_keys, want_perm=True)
 
 
+@pytest.mark.parametrize("tag", ["mixed4", "molhiv4", "zinc3"])
+def test_dataloader_pins_the_dataset_and_yields_the_same_batches(E, tag):
+    """the reference's loop `for data in DataLoader(dataset, bs, shuffle=True): data = data.to(device)`
+    (dataloader.py:11-48, run_graphcount.py:453-455,487): with a HIP device the loader collates on the device from a
+    pinned copy — same graphs in the same (seeded) order, every tensor bit-identical to the host collate moved over"""
+    graphs, _, _ = load_collate(tag)
+    datas = [E.Data(**{k: torch.tensor(v) for k, v in g.items()}) for g in graphs] * 3
+    fast = E.DataLoader(datas, batch_size=5, shuffle=True)
+    host = E.DataLoader(datas, batch_size=5, shuffle=True, device=None)
+    for epoch in range(2):
+        torch.manual_seed(100 + epoch)
+        got = list(fast)
+        torch.manual_seed(100 + epoch)
+        want = list(host)
+        assert len(got) == len(want) == -(-len(datas) // 5) and fast.__dict__["_esc_store"] is not False
+        for a, b in zip(got, want):
+            assert sorted(a.keys) == sorted(b.keys) and a.num_graphs == b.num_graphs
+            for k in b.keys:
+                assert a[k].is_cuda and not b[k].is_cuda
+                assert a[k].dtype == b[k].dtype and torch.equal(a[k].cpu(), b[k]), (epoch, k)
+            assert a.to(DEV) is a and "_esc_plan" in a.__dict__          # the caller's .to(device) keeps the collate's plan
+            back = a.to_data_list()
+            assert len(back) == a.num_graphs
+    # what the device store cannot reproduce stays on the reference's host path
+    assert E.DataLoader(datas, batch_size=5, follow_batch=["pos_enc"]).__iter__().__class__.__name__ != "generator"
+    odd = [E.Data(x=torch.ones(2, 1), edge_index=torch.tensor([[0], [1]]), mask=torch.tensor([True, False]))] * 4
+    assert not next(iter(E.DataLoader(odd, batch_size=2))).x.is_cuda
+
+
 def test_reference_data_slices_layout_round_trip(E, tmp_path):
     """the reference's InMemoryDataset cache is `torch.save((data, slices), path)` (GraphCountDataset.py:119-120): the
     store writes that layout as plain tensors (loadable with weights_only=True), reads it back — from a dict or from an

@@ -115,6 +115,33 @@ def _model(E, seed=0):
     return m
 
 
+# how many gradient tensors were SEEN to need the ReLU-kink (Frobenius) criterion on the MI355X test box with these seeds
+# (printed by the tests; the assertions hold the observed counts, not a generous cap)
+KINKED_SEEN = {"engine_vs_fp64": 2, "engine_vs_per_op": 4, "x_ones_vs_fp64": 2}
+
+
+def _grads_vs_fp64(mine, ref, ref64, frob, skip=lambda n: False):
+    """every gradient as accurate as the fp32 CPU oracle (error vs the fp64 oracle <= max(1e-5, 3x the fp32 oracle's own
+    error)); a tensor that fails that must pass the relative Frobenius test (a ReLU-kink tie is a rank-one change that is
+    large in max-norm and ~1/sqrt(rows*H) in Frobenius norm).  Returns the names that needed the second criterion."""
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    kinked = []
+    for n, p in mine.named_parameters():
+        if skip(n):
+            continue
+        truth = g64[n].grad
+        sc = max(1.0, float(truth.abs().max()))
+        diff = p.grad.detach().cpu().double() - truth
+        e_mine = float(diff.abs().max()) / sc
+        e_ref = float((g32[n].grad.double() - truth).abs().max()) / sc
+        if e_mine <= max(1e-5, 3 * e_ref):
+            continue
+        rel_f = float(diff.norm()) / max(float(truth.norm()), 1e-12)
+        assert rel_f <= frob, "grad %s: HIP error %.3g vs fp32-oracle error %.3g, relative Frobenius %.3g" % (n, e_mine, e_ref, rel_f)
+        kinked.append(n)
+    return kinked
+
+
 def _randomise_x(batch):
     g = torch.Generator(device=DEV).manual_seed(5)
     batch.x = torch.randn(batch.x.shape, device=DEV, generator=g)
@@ -160,33 +187,77 @@ def test_train_step_against_fp64_oracle_at_full_size(E, world):
     # activations pass through each ReLU, so now and then ONE pre-activation sits within fp32 rounding of zero and the two
     # fp32 implementations pick different sides of the kink: a rank-one difference (one row's g, g*x) that is large in
     # max-norm but negligible in Frobenius norm.  Such tensors must pass the Frobenius test, and only a few may need it.
-    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
-    kinked = []
-    for n, p in mine.named_parameters():
-        truth = g64[n].grad
-        sc = max(1.0, float(truth.abs().max()))
-        diff = p.grad.detach().cpu().double() - truth
-        e_mine = float(diff.abs().max()) / sc
-        e_ref = float((g32[n].grad.double() - truth).abs().max()) / sc
-        if e_mine <= max(1e-5, 3 * e_ref):
-            continue
-        rel_f = float(diff.norm()) / max(float(truth.norm()), 1e-12)
-        assert rel_f <= 1e-3, "grad %s: HIP error %.3g vs fp32-oracle error %.3g, relative Frobenius %.3g" % (n, e_mine, e_ref, rel_f)
-        kinked.append(n)
-    assert len(kinked) <= 4, kinked
+    kinked = _grads_vs_fp64(mine, ref, ref64, frob=1e-3)
+    print("full-size step vs fp64 oracle: %d of %d gradient tensors needed the Frobenius (ReLU-kink) criterion: %s"
+          % (len(kinked), len(list(mine.parameters())), kinked))
+    assert len(kinked) <= KINKED_SEEN["engine_vs_fp64"], kinked
     # the per-op autograd path is a second implementation of the same step
     twin.train()
     lt = E.ops.l1_loss(twin(b), b.y)
     lt.backward()
     assert abs(float(lt.detach()) - float(loss.detach())) <= 1e-5 * max(1.0, abs(float(lt.detach())))
+    # engine vs per-op path: the TIGHT criterion first — both as accurate as the fp32 oracle against the fp64 truth, i.e. within
+    # max(2e-5, 6x the fp32 oracle's error) of each other — and only for a tensor that fails it the ReLU-kink allowance: the two
+    # paths round a pre-activation differently (fmaf(y, scale, shift) inside the consumer GEMM vs a materialised BatchNorm
+    # output), an element within an ulp of the kink may be clipped by one and not by the other, and one such flip is a
+    # rank-one change of relative size 1/sqrt(rows*H) in every gradient upstream of it (1.3e-3 at node size, 5e-4 at edge
+    # size) — relative Frobenius <= 5e-3, and the NUMBER of such tensors is bounded by what this seed was seen to need.
     tw = dict(twin.named_parameters())
-    # Frobenius norm, 5e-3: the two paths round a pre-activation differently (fmaf(y, scale, shift) inside the consumer GEMM
-    # vs a materialised BatchNorm output), so an element within an ulp of a ReLU kink may be clipped by one and not by the
-    # other.  One such flip is a rank-one change of relative size 1/sqrt(rows*H) in every gradient upstream of it:
-    # 1.3e-3 at node size (2 400 rows), 5e-4 at edge size.  Measured over six input seeds: engine and autograd path are
-    # each within 5e-7 of the fp64 oracle on most seeds and 2.3e-3 (two flips in x_embedding) on one.
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    loose = []
     for n, p in mine.named_parameters():
-        assert float((p.grad - tw[n].grad).norm()) <= 5e-3 * float(tw[n].grad.norm()) + 1e-5, n
+        truth = g64[n].grad
+        sc = max(1.0, float(truth.abs().max()))
+        e_ref = float((g32[n].grad.double() - truth).abs().max()) / sc
+        d = (p.grad - tw[n].grad).detach().cpu().double()
+        if float(d.abs().max()) / sc <= max(2e-5, 6 * e_ref):
+            continue
+        assert float(d.norm()) <= 5e-3 * float(tw[n].grad.norm()) + 1e-5, n
+        loose.append(n)
+    print("engine vs per-op path: %d tensors needed the ReLU-kink allowance: %s" % (len(loose), loose))
+    assert len(loose) <= KINKED_SEEN["engine_vs_per_op"], loose
+
+
+def test_train_step_on_the_benchmark_input_x_ones_at_full_size(E, world):
+    """The EXACT workload bench.py times: x = ones[n,10] (GraphCountDataset.py:84), bs=128, h=3, L=4, H=256.  That input makes
+    every row entering x_embedding's BatchNorms identical (zero batch variance): their gradients are mathematically zero
+    and the CPU oracle returns rounding noise amplified by eps^-1/2 = 316 there, so those tensors are only required to be
+    tiny on both sides (tests/test_hip_model.py::_degenerate); predictions, loss and every other gradient are held to the
+    full-size criterion."""
+    import copy
+    import ref_model as rm
+    store, bs = world["store"], world["bs"]
+    b = store.collate(torch.arange(bs))
+    assert bool((b.x == 1).all()) and b.x.shape[1] == 10
+    torch.manual_seed(23)
+    ref = rm.NestedGINEffRef(4, 256)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1 and "bias" not in n:
+                p.add_(0.1 * torch.randn_like(p))
+    mine = E.NestedGIN_eff(None, 4, 256, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV).train()
+    cpu = {k: b[k].cpu() for k in ("x", "edge_index", "pos_enc", "pos_index", "pos_batch", "batch", "y")}
+    ref.train()
+    pr = ref(cpu["x"], cpu["edge_index"], cpu["pos_enc"], cpu["pos_index"], cpu["pos_batch"], cpu["batch"])
+    torch.nn.functional.l1_loss(pr, cpu["y"].view(-1, 1)).backward()
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad()
+    p64 = ref64(cpu["x"].double(), cpu["edge_index"], cpu["pos_enc"], cpu["pos_index"], cpu["pos_batch"], cpu["batch"])
+    l64 = torch.nn.functional.l1_loss(p64, cpu["y"].double().view(-1, 1))
+    l64.backward()
+    loss, pred = E.StepEngine(mine).train_step(b, return_pred=True)
+    scale = max(1.0, float(p64.abs().max()))
+    assert float((pred.detach().cpu().double() - p64.detach()).abs().max()) / scale <= 1e-5
+    assert abs(float(loss.detach()) - float(l64.detach())) <= 1e-5 * max(1.0, abs(float(l64.detach())))
+    degenerate = lambda n: n.startswith("x_embedding.") and n != "x_embedding.6.bias"
+    for n, p in mine.named_parameters():
+        if degenerate(n):
+            assert float(p.grad.abs().max()) < 1e-2 and float(dict(ref.named_parameters())[n].grad.abs().max()) < 1e-2, n
+    kinked = _grads_vs_fp64(mine, ref, ref64, frob=1e-3, skip=degenerate)
+    print("x = ones full-size step vs fp64 oracle: %d tensors needed the Frobenius criterion: %s" % (len(kinked), kinked))
+    assert len(kinked) <= KINKED_SEEN["x_ones_vs_fp64"], kinked
 
 
 def test_loss_invariant_under_graph_permutation(E, world):

@@ -67,7 +67,9 @@ def _grad_check(named_mine, g32, g64, max_kinked=6):
         rel_f = float(diff.norm()) / max(float(truth.norm()), 1e-12)
         assert rel_f <= 5e-3, "grad %s: HIP error %.3g vs fp32-oracle error %.3g, relative Frobenius %.3g" % (n, e_mine, e_ref, rel_f)
         kinked.append(n)
+    print("molecule full-size step vs fp64 oracle: %d tensors needed the Frobenius (ReLU-kink) criterion: %s" % (len(kinked), kinked))
     assert len(kinked) <= max_kinked, kinked
+    return kinked
 
 
 def test_config4_zinc_layers5_bs128(E):
@@ -116,12 +118,17 @@ def test_config4_zinc_layers5_bs128(E):
     assert abs(float(loss.detach()) - float(l64.detach())) <= 1e-5 * max(1.0, abs(float(l64.detach())))
     _grad_check(mine.named_parameters(), {n: p.grad for n, p in ref.named_parameters()},
                 {n: p.grad for n, p in ref64.named_parameters()})
-    # eval mode on the running statistics
-    mine.eval(); ref.eval()
+    # eval mode on the running statistics: against the fp64 oracle evaluated on THE SAME buffers (the module's own running
+    # statistics and parameters after the step above), so that only the arithmetic of the eval forward is compared: 1e-5.
+    # (Against the fp32 oracle's own buffers the two differ by what one momentum update in fp32 leaves: 1e-4 was r02's bound.)
+    mine.eval()
+    ev64 = copy.deepcopy(ref).double()
+    ev64.load_state_dict({k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in mine.state_dict().items()})
+    ev64.eval()
     with torch.no_grad():
         e_m = mine(store.collate(torch.arange(bs)))
-        e_r = ref(cpu["x"], cpu["edge_index"], cpu["edge_attr"], cpu["pos_enc"], cpu["pos_index"], cpu["pos_batch"], cpu["batch"])
-    assert float((e_m.cpu() - e_r).abs().max()) <= 1e-4 * max(1.0, float(e_r.abs().max()))
+        e_r = ev64(cpu["x"], cpu["edge_index"], cpu["edge_attr"], cpu["pos_enc"], cpu["pos_index"], cpu["pos_batch"], cpu["batch"])
+    assert float((e_m.cpu().double() - e_r).abs().max()) <= 1e-5 * max(1.0, float(e_r.abs().max()))
 
 
 def test_config5_molhiv_h4_layers6_emb300_bs256(E):
@@ -163,3 +170,16 @@ def test_config5_molhiv_h4_layers6_emb300_bs256(E):
     assert abs(float(loss.detach()) - float(l64.detach())) <= 1e-5 * max(1.0, abs(float(l64.detach())))
     _grad_check(mine.named_parameters(), {n: p.grad for n, p in ref.named_parameters()},
                 {n: p.grad for n, p in ref64.named_parameters()})
+
+
+def test_config5_full_size_with_dropout_through_the_mask_replay(E):
+    """config 5 at its stated size (bs=256, h=4, L=6, emb 300) WITH dropout (0.5): the engine's counter-based masks are
+    regenerated on the host and applied on the per-op path (tests/test_hip_model.py::_ogb_engine_vs_per_op), so logits, loss,
+    every gradient and the BatchNorm buffers of the two implementations must agree at full size too"""
+    from esc_gnn_amd.datasets import build_feature_dataset, synthetic_ogbmol_graphs
+    from test_hip_model import _ogb_engine_vs_per_op
+    bs = 256
+    graphs = build_feature_dataset(synthetic_ogbmol_graphs(0, bs), 4, use_rd=True, self_loop=True)
+    b = E.DeviceGraphStore(graphs, DEV).collate(torch.arange(bs))
+    bt = {k: b[k].cpu() for k in ("x", "edge_index", "edge_attr", "y", "pos_enc", "pos_index", "pos_batch", "batch")}
+    _ogb_engine_vs_per_op(bt, 6, 300, 0.5, True, "mean", max_kinked=8)

@@ -461,14 +461,17 @@ def test_ogb_step_engine_matches_per_op_path(p, residual, pooling, mol_streams):
     path apply them (z_embedding's Dropout modules and the F.dropout calls of the node / virtual-node updates, in the
     engine's numbering), so loss, logits, every gradient and the BatchNorm buffers must agree."""
     require_gpu()
+    _, b, _ = load_collate("molhiv4")
+    _ogb_engine_vs_per_op({k: torch.tensor(v) for k, v in b.items()}, 3, 32, p, residual, pooling)
+
+
+def _ogb_engine_vs_per_op(bt, L, H, p, residual, pooling, max_kinked=None):
+    """the comparison above on any batch / model size (tests/test_hip_fullsize_mol.py runs it at BASELINE config 5's)"""
     import copy
     import esc_gnn_amd as E
     from esc_gnn_amd import ogb_mol_gnn as og
     from esc_gnn_amd.engine import OgbStepEngine
     torch.manual_seed(11)
-    L, H = 3, 32
-    _, b, _ = load_collate("molhiv4")
-    bt = {k: torch.tensor(v) for k, v in b.items()}
     m1 = og.GNN("ogbg-molhiv", 1, num_layer=L, emb_dim=H, gnn_type="gin_eff", virtual_node=True, residual=residual,
                 drop_ratio=p, JK="last", graph_pooling=pooling).to("cuda:0").train()
     with torch.no_grad():
@@ -521,12 +524,18 @@ def test_ogb_step_engine_matches_per_op_path(p, residual, pooling, mol_streams):
     _close(pred2, out.detach().cpu(), "engine logits vs per-op")
     assert abs(float(loss1.detach()) - float(loss2)) <= 1e-5 * max(1.0, abs(float(loss1.detach())))
     g1 = dict(m1.named_parameters())
+    kinked = []
     for n, q in m2.named_parameters():
         ref = g1[n].grad.cpu()
         diff = q.grad.cpu() - ref
         sc = max(1.0, float(ref.abs().max()))
-        ok = float(diff.abs().max()) / sc <= 2e-5 or float(diff.norm()) / max(float(ref.norm()), 1e-12) <= 5e-3   # ReLU-kink tie
-        assert ok, "grad %s: %.3g" % (n, float(diff.abs().max()) / sc)
+        if float(diff.abs().max()) / sc <= 2e-5:
+            continue
+        assert float(diff.norm()) / max(float(ref.norm()), 1e-12) <= 5e-3, "grad %s: %.3g" % (n, float(diff.abs().max()) / sc)   # ReLU-kink tie
+        kinked.append(n)
+    print("OGB engine vs per-op path (p=%g, L=%d, H=%d): %d tensors needed the ReLU-kink allowance: %s" % (p, L, H, len(kinked), kinked))
+    if max_kinked is not None:
+        assert len(kinked) <= max_kinked, kinked
     b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
     for n, a in b2.items():
         if a.is_floating_point():

@@ -670,7 +670,7 @@ def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(
     for affine in (False, True):
         de = torch.empty(Ee, C, device=dev)
         dx = torch.full((N, C), 0.25, device=dev)            # accumulate_dx = 1: added onto what is there
-        dp = torch.empty(N, device=dev)
+        dp = torch.empty(N * int(nv.lib().esc_gine_aggregate_bwd_deps_slots(C)), device=dev)
         if affine:
             nv.call("esc_gine_aggregate_bwd_affine", nv.ptr(x), ld, nv.ptr(sc), nv.ptr(sh), nv.ptr(e), C, nv.ptr(g), C, nv.ptr(plan.out_ptr),
                     nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, C, nv.ptr(de), C, nv.ptr(dx), C, 1, nv.ptr(dp), s)
@@ -683,3 +683,146 @@ def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(
     with pytest.raises(RuntimeError):                        # narrow rows have no affine variant
         nv.call("esc_gine_aggregate_fwd_affine", nv.ptr(x), ld, nv.ptr(sc), nv.ptr(sh), nv.ptr(e), C, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge),
                 nv.ptr(plan.in_src), nv.ptr(eps), N, 32, nv.ptr(got), C, s)
+
+
+@pytest.mark.parametrize("M,N,K,relu,pro,acc,nxt", [
+    (2400, 256, 256, 1, True, 0, True),      # GINEConv.nn.4 backward: BatchNorm1 apply in front, BatchNorm0 sums behind
+    (2400, 256, 256, 1, False, 1, False),    # ... accumulating dX
+    (2400, 256, 1024, 1, True, 0, False),    # readout lin1, the edge stream's column block
+    (2400, 256, 10, 1, False, 0, False),     # conv1.nn.0 / x_embedding.0: the narrow-input kernels
+    (77, 64, 96, 0, False, 0, True),         # ragged rows, no activation
+    (1500, 300, 600, 1, True, 0, True),      # widths that are not multiples of the 32-wide K-step
+    (333, 128, 16, 1, True, 0, False),
+])
+def test_linear_backward_with_batchnorm_backward_folded_in(E, M, N, K, relu, pro, acc, nxt):
+    """esc_linear_bwd_both_bn == esc_bn_bwd_apply -> esc_linear_bwd_both (run_graphcount.py:65-73,78-87,183-186 backward):
+    the BatchNorm backward is applied to the dY operand as the GEMM stages it; with `next` the dX tiles leave the column
+    sums of the next BatchNorm backward.  Checked against the unfused C-ABI sequence and an fp64 autograd reference."""
+    import ctypes
+    nv = E._native
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M * 7 + N + K)
+    xb = (torch.randn(M, N) * 1.5 + 0.3).to(dev)                 # what the BatchNorm normalised
+    gamma, beta = (torch.rand(N) + 0.5).to(dev), (torch.randn(N) * 0.3).to(dev)
+    dOut = torch.randn(M, N).to(dev)
+    ldx = K + 8                                                  # a slice of a wider buffer, like the concat slices
+    Xw = torch.randn(M, ldx).to(dev)
+    X = Xw[:, :K]
+    W = (torch.randn(N, K) / K ** 0.5).to(dev)
+    isc, ish = ((torch.rand(K) + 0.5).to(dev), (torch.randn(K) * 0.2).to(dev)) if pro else (None, None)
+    scratch = torch.empty(nv.lib().esc_bn_scratch(max(N, K)), device=dev)
+
+    def stats(x, C, ga, be):       # the library's own statistics / forward coefficients (what the engine hands on)
+        out = [torch.empty(C, device=dev) for _ in range(4)]
+        nv.call("esc_bn_stats", nv.ptr(x), C, M, C, 1e-5, 0.1, nv.ptr(out[0]), nv.ptr(out[1]), None, None, nv.ptr(ga), nv.ptr(be),
+                nv.ptr(out[2]), nv.ptr(out[3]), nv.ptr(scratch), nv.stream())
+        return out
+    mean, invstd, scale, shift = stats(xb, N, gamma, beta)
+    coef, dg, db_bn = torch.empty(N, 2, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    nv.call("esc_bn_bwd_coef", nv.ptr(xb), N, None, 0, nv.ptr(dOut), N, M, N, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+            relu, nv.ptr(coef), nv.ptr(dg), nv.ptr(db_bn), nv.ptr(scratch), nv.stream())
+    dx0 = torch.randn(M, K).to(dev) if acc else torch.zeros(M, K, device=dev)
+    x2 = (torch.randn(M, K) * 0.8 - 0.2).to(dev)                 # input rows of the NEXT BatchNorm (over dX's K channels)
+    g2, b2 = (torch.rand(K) + 0.5).to(dev), (torch.randn(K) * 0.3).to(dev)
+    mean2, invstd2, scale2, shift2 = stats(x2, K, g2, b2)
+    slab_n = int(nv.lib().esc_linear_bwd_weight_scratch(M, N, K))
+
+    def unfused():
+        dY = torch.empty(M, N, device=dev)
+        nv.call("esc_bn_bwd_apply", nv.ptr(xb), N, None, 0, nv.ptr(dOut), N, M, N, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(beta),
+                relu, nv.ptr(coef), nv.ptr(dY), N, nv.stream())
+        dX, dW, db = dx0.clone(), torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        slabs = torch.empty(slab_n, device=dev)
+        nv.call("esc_linear_bwd_both", nv.ptr(dY), N, nv.ptr(X), ldx, nv.ptr(isc), nv.ptr(ish), nv.ptr(W), K, M, N, K, nv.ptr(dX), K, acc,
+                nv.ptr(dW), K, nv.ptr(db), nv.ptr(slabs), nv.stream())
+        return dX, dW, db, dY
+
+    f = nv.BnBwdFused()
+    f.x, f.ld_x, f.mean, f.invstd, f.scale, f.shift, f.coef, f.relu = xb.data_ptr(), N, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), coef.data_ptr(), relu
+    nx = None
+    if nxt:
+        rows = int(nv.lib().esc_linear_bwd_bn_block_rows(M, N, K))
+        slots = -(-M // rows)
+        partial = torch.full((slots, K, 2), float("nan"), device=dev)
+        nx = nv.BnBwdNext()
+        nx.partial, nx.x, nx.ld_x, nx.mean, nx.invstd, nx.scale, nx.shift, nx.relu = partial.data_ptr(), x2.data_ptr(), K, mean2.data_ptr(), invstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), 1
+    slabs = torch.empty(slab_n, device=dev)
+    dX, dW, db = dx0.clone(), torch.full((N, K), float("nan"), device=dev), torch.full((N,), float("nan"), device=dev)
+    assert nv.lib().esc_linear_bwd_both_bn_ok(nv.ptr(dOut), N, ctypes.byref(f), nv.ptr(X), ldx, nv.ptr(W), K, M, N, K, nv.ptr(dX), K, nv.ptr(slabs),
+                                              ctypes.byref(nx) if nx is not None else None) == 1
+    nv.call("esc_linear_bwd_both_bn", nv.ptr(dOut), N, ctypes.byref(f), nv.ptr(X), ldx, nv.ptr(isc), nv.ptr(ish), nv.ptr(W), K, M, N, K,
+            nv.ptr(dX), K, acc, nv.ptr(dW), K, nv.ptr(db), nv.ptr(slabs), None, ctypes.byref(nx) if nx is not None else None, nv.stream())
+    uX, uW, ub, dY = unfused()
+    scale_of = lambda t: max(1.0, float(t.abs().max()))
+    for a, b, name in ((dX, uX, "dX"), (dW, uW, "dW")):
+        assert float((a - b).abs().max()) <= 2e-5 * scale_of(b), (name, float((a - b).abs().max()), scale_of(b))
+    # the bias gradient of a Linear in front of a BatchNorm is zero up to rounding (column sums of a BatchNorm backward)
+    assert float((db - ub).abs().max()) <= 1e-3 and float(db.abs().max()) <= 1e-2 * scale_of(dY) * M ** 0.5
+    # fp64 reference of the whole chain
+    xb64, ga64, be64 = xb.double().cpu().requires_grad_(True), gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    X64 = X.double().cpu()
+    Xa = (torch.relu(X64 * isc.double().cpu() + ish.double().cpu()) if pro else X64).requires_grad_(True)
+    W64 = W.double().cpu().requires_grad_(True)
+    # (Linear in front of the BatchNorm is irrelevant here: treat the BatchNorm input as a leaf and chain by hand)
+    y = torch.nn.functional.batch_norm(xb64, None, None, ga64, be64, True, 0.1, 1e-5)
+    y = y.relu() if relu else y
+    y.backward(dOut.double().cpu())
+    dY64 = xb64.grad
+    _chk(dY, dY64, "unfused dY")
+    _chk(dg, ga64.grad, "dgamma")
+    _chk(db_bn, be64.grad, "dbeta")
+    want_dX = dY64 @ W64.detach() + (dx0.double().cpu() if acc else 0)
+    want_dW = dY64.t() @ Xa.detach()
+    _chk(dX, want_dX, "fused dX vs fp64")
+    _chk(dW, want_dW, "fused dW vs fp64", tol=2e-5)
+    if nxt:
+        c2, dg2, db2 = torch.empty(K, 2, device=dev), torch.empty(K, device=dev), torch.empty(K, device=dev)
+        nv.call("esc_bn_bwd_coef_from_partials", nv.ptr(partial), slots, M, K, nv.ptr(c2), nv.ptr(dg2), nv.ptr(db2), nv.stream())
+        r2, rg2, rb2 = torch.empty(K, 2, device=dev), torch.empty(K, device=dev), torch.empty(K, device=dev)
+        nv.call("esc_bn_bwd_coef", nv.ptr(x2), K, None, 0, nv.ptr(dX), K, M, K, nv.ptr(mean2), nv.ptr(invstd2), nv.ptr(g2), nv.ptr(b2),
+                1, nv.ptr(r2), nv.ptr(rg2), nv.ptr(rb2), nv.ptr(scratch), nv.stream())
+        assert not bool(torch.isnan(partial).any())
+        for a, b, name in ((c2, r2, "coef"), (dg2, rg2, "dgamma"), (db2, rb2, "dbeta")):
+            assert float((a - b).abs().max()) <= 1e-5 * scale_of(b) * max(1.0, M ** 0.5 / 10), (name, float((a - b).abs().max()))
+
+
+def test_linear_backward_leaves_the_next_batchnorm_sums_without_a_fused_apply(E):
+    """esc_linear_bwd_both_bn(bn=NULL, next): a plain dY, only the column sums of the NEXT BatchNorm backward ride in the dX
+    epilogue — dX / dW bit-identical to esc_linear_bwd_both, the sums equal to esc_bn_bwd_coef's"""
+    import ctypes
+    nv = E._native
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    M, N, K = 2400, 256, 256
+    dY, X, W = torch.randn(M, N).to(dev), torch.randn(M, K).to(dev), (torch.randn(N, K) / 16).to(dev)
+    x2 = (torch.randn(M, K) * 0.8 - 0.2).to(dev)
+    g2, b2 = (torch.rand(K) + 0.5).to(dev), (torch.randn(K) * 0.3).to(dev)
+    scratch = torch.empty(nv.lib().esc_bn_scratch(K), device=dev)
+    st = [torch.empty(K, device=dev) for _ in range(4)]
+    nv.call("esc_bn_stats", nv.ptr(x2), K, M, K, 1e-5, 0.1, nv.ptr(st[0]), nv.ptr(st[1]), None, None, nv.ptr(g2), nv.ptr(b2), nv.ptr(st[2]), nv.ptr(st[3]),
+            nv.ptr(scratch), nv.stream())
+    slab_n = int(nv.lib().esc_linear_bwd_weight_scratch(M, N, K))
+    out = []
+    for fused in (False, True):
+        dX, dW, db = torch.empty(M, K, device=dev), torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        slabs = torch.empty(slab_n, device=dev)
+        if fused:
+            slots = -(-M // int(nv.lib().esc_linear_bwd_bn_block_rows(M, N, K)))
+            partial = torch.full((slots, K, 2), float("nan"), device=dev)
+            nx = nv.BnBwdNext()
+            nx.partial, nx.x, nx.ld_x, nx.mean, nx.invstd, nx.scale, nx.shift, nx.relu = partial.data_ptr(), x2.data_ptr(), K, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), 1
+            nv.call("esc_linear_bwd_both_bn", nv.ptr(dY), N, None, nv.ptr(X), K, None, None, nv.ptr(W), K, M, N, K, nv.ptr(dX), K, 0, nv.ptr(dW), K,
+                    nv.ptr(db), nv.ptr(slabs), None, ctypes.byref(nx), nv.stream())
+        else:
+            nv.call("esc_linear_bwd_both", nv.ptr(dY), N, nv.ptr(X), K, None, None, nv.ptr(W), K, M, N, K, nv.ptr(dX), K, 0, nv.ptr(dW), K, nv.ptr(db),
+                    nv.ptr(slabs), nv.stream())
+        out.append((dX, dW, db))
+    for a, b, name in zip(out[0], out[1], ("dX", "dW", "db")):
+        assert torch.equal(a, b), name
+    c2, dg2, db2 = torch.empty(K, 2, device=dev), torch.empty(K, device=dev), torch.empty(K, device=dev)
+    nv.call("esc_bn_bwd_coef_from_partials", nv.ptr(partial), slots, M, K, nv.ptr(c2), nv.ptr(dg2), nv.ptr(db2), nv.stream())
+    r2, rg2, rb2 = torch.empty(K, 2, device=dev), torch.empty(K, device=dev), torch.empty(K, device=dev)
+    nv.call("esc_bn_bwd_coef", nv.ptr(x2), K, None, 0, nv.ptr(out[1][0]), K, M, K, nv.ptr(st[0]), nv.ptr(st[1]), nv.ptr(g2), nv.ptr(b2), 1, nv.ptr(r2),
+            nv.ptr(rg2), nv.ptr(rb2), nv.ptr(scratch), nv.stream())
+    for a, b, name in ((c2, r2, "coef"), (dg2, rg2, "dgamma"), (db2, rb2, "dbeta")):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), name

@@ -111,7 +111,7 @@ def test_reference_style_loop_with_torch_loss_and_optimizer():
     y = torch.cat([g.y for g in graphs]); mean, std = y.mean(), y.std()
     for g in graphs:
         g.y = (g.y - mean) / std
-    loader = E.DataLoader(graphs, batch_size=16, shuffle=False)            # host collate, like the reference
+    loader = E.DataLoader(graphs, batch_size=16, shuffle=False)            # the reference's loader call; batches are collated on the device from a pinned copy
     model = E.NestedGIN_eff(None, 3, 64, use_rd=True, graph_pred=False, dropout=0, edge_nest=True, use_cycle=True).to("cuda:0")
     optimizer = torch.optim.Adam(model.parameters(), lr=5e-3)
     losses = []

@@ -100,7 +100,7 @@ def main():
     g = torch.randn(N, H, device=dev)
     de = torch.empty(Ee, H, device=dev)
     dx = torch.zeros(N, H, device=dev)
-    dp = torch.empty(N, device=dev)
+    dp = torch.empty(2 * N, device=dev)
     us, k = timed("agg_bwd", lambda: nv.call("esc_gine_aggregate_bwd", nv.ptr(x), H, nv.ptr(e), H, nv.ptr(g), H, nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, H, nv.ptr(de), H, nv.ptr(dx), H, 1, nv.ptr(dp), s))
     add("aggregate backward, cache-resident", us, k, 2 * Ee * H * 4 + 3 * N * H * 4 + Ee * 8)
     sets = [(torch.randn(N, H, device=dev), torch.randn(Ee, H, device=dev), torch.randn(N, H, device=dev), torch.empty(Ee, H, device=dev),
