@@ -140,8 +140,9 @@ def main():
         strong scaling: ONE global batch of --batch_size graphs per step, rank r collates its contiguous
         slice [r*B/W, (r+1)*B/W) of it (run_graphcount.py's data-parallel mode)."""
         ids = batch_ids[i % nb]
-        if mode["scaling"] == "strong" and world > 1:
-            lo, hi = E.parallel.shard_slice(ids.numel(), rank, world)
+        if mode["scaling"] == "strong" and world > 1:         # contiguous slices of near-equal EDGE count (the step's cost is edge-sized work)
+            ep = mode["store"].h_edge_ptr
+            lo, hi = E.parallel.shard_slice_balanced((ep[ids + 1] - ep[ids]).tolist(), rank, world)
             return ids[lo:hi]
         return ids
 

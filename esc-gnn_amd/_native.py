@@ -60,6 +60,8 @@ SIGNATURES = {
     "esc_prof_reset": [I32],
     "esc_prof_read_all": [I32, POINTER(c_double), c_int64],
     "esc_bag_fwd": [P, I64, P, P, P, I64, P, I64, P],
+    "esc_bag_fwd_rows": [P, I64, I64, P, P, P, I64, P, I64, I32, P, P],
+    "esc_bag_fwd_stats_block_rows": [P, I64, I64, P, I64, I64],
     "esc_bag_bwd_scratch": [I64, I64],
     "esc_bag_bwd_table": [P, I64, I64, P, P, P, P, I64, I64, P, P, P],
     "esc_bag_bwd_classify": [P, I64, I64, I64, P, P],
@@ -129,6 +131,8 @@ SIGNATURES = {
     "esc_engine_set_two_stream_min_edges": [I64],
     "esc_gine_aggregate_fwd_affine": [P, I64, P, P, P, I64, P, P, P, P, I64, I64, P, I64, P],
     "esc_gine_aggregate_bwd_affine": [P, I64, P, P, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P],
+    "esc_gine_aggregate_bwd_stats_slots": [I64],
+    "esc_gine_aggregate_bwd_affine_stats": [P, I64, P, P, P, P, P, I64, P, I64, P, P, P, P, I64, I64, P, I64, P, I64, I32, P, P, P],
     "esc_embed_fwd": [P, I64, I64, P, I64, P, I64, P, P],
     "esc_embed_bwd": [P, I64, P, I64, I64, I64, P, P],
     "esc_zinc_workspace_floats": [P, I64, I64, I64, I64],
@@ -154,7 +158,7 @@ SIGNATURES = {
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
-_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_embed_plan_scratch": c_int64, "esc_prof_read_all": c_int64,
+_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_bag_fwd_stats_block_rows": c_int64, "esc_gine_aggregate_bwd_stats_slots": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_embed_plan_scratch": c_int64, "esc_prof_read_all": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64, "esc_linear_bwd_bn_block_rows": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64,
         "esc_zinc_workspace_floats": c_int64, "esc_ogb_workspace_floats": c_int64}

@@ -157,7 +157,11 @@ __global__ __launch_bounds__(256) void agg_fwd_elem(const float* __restrict__ x,
 
 // ---- backward: one wave per SOURCE node (out-CSR) -------------------------------------------------
 // each edge has exactly one source, so d_e[k] is written exactly once and dx[i] needs no atomics.
-template <int VEC, bool AFF = false>
+// BST (with AFF, dx != NULL, accumulate or not): dx is then the FINAL gradient of the BatchNorm(+ReLU) output x' whose
+// pre-activation rows are x, so the column sums of that BatchNorm's backward — (sum g, sum g*xhat), g = dx * [x' > 0],
+// xhat = (x - mean) * invstd — are taken here, per workgroup (4 source rows), and the separate partial-sum pass over
+// dx and x before the finalize disappears from the node chain: partial[blockIdx.x][c] (float2).
+template <int VEC, bool AFF = false, bool BST = false>
 __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x, int64_t ld_x,
                                                     const float* __restrict__ e, int64_t ld_e,
                                                     const float* __restrict__ g, int64_t ld_g,
@@ -168,13 +172,31 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
                                                     float* __restrict__ d_e, int64_t ld_de,
                                                     float* __restrict__ dx, int64_t ld_dx, int accumulate_dx,
                                                     float* __restrict__ deps_part,
-                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift, int split) {
+                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift, int split,
+                                                    const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd,
+                                                    float2* __restrict__ bn_partial) {
   ESC_PRIO();
+  static_assert(!BST || AFF, "the BatchNorm sums need the pre-activation rows");
+  extern __shared__ __attribute__((aligned(16))) float2 bst_sh[];        // BST: [4 waves][C]
   // split > 1: as in agg_fwd_wave — `split` waves share a source row, C / split columns each; deps_part then holds
   // N * split partial dot products (wave w writes deps_part[w])
   const int wid = uniform((int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6));
   const int node = wid / split;
-  if (node >= N) return;
+  if constexpr (BST) {
+    if (node >= N) {                                  // an idle wave of the last workgroup still feeds the workgroup's sum (zeros)
+      for (int c = lane_id(); c < C; c += WAVE) bst_sh[(threadIdx.x >> 6) * C + c] = make_float2(0.f, 0.f);
+      __syncthreads();                                // ... and takes its share of the columns in the final pass
+      for (int c = threadIdx.x; c < C; c += 256) {
+        float2 a = bst_sh[c];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float2 b = bst_sh[w * C + c]; a.x += b.x; a.y += b.y; }
+        bn_partial[(size_t)blockIdx.x * C + c] = a;
+      }
+      return;
+    }
+  } else {
+    if (node >= N) return;
+  }
   const int cw = C / split, c_lo = (wid - node * split) * cw, c_hi = c_lo + cw;
   const int lane = lane_id();
   const int beg = uniform(out_ptr[node]);
@@ -183,10 +205,12 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
   const float one_eps = has_self ? 1.0f + *eps_p : 0.f;
   float dot = 0.f;
   for (int c = c_lo + lane * VEC; c < c_hi; c += WAVE * VEC) {
-    float xi[VEC], gi[VEC], acc[VEC];
+    float xi[VEC], gi[VEC], acc[VEC], xraw[VEC];
     {
       row_load<VEC>(x + (size_t)node * ld_x + c, xi);
       row_load<VEC>(g + (size_t)node * ld_g + c, gi);
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) xraw[t] = xi[t];
       if constexpr (AFF) {                                  // x is the pre-activation row: the layer input is relu(x*scale+shift)
 #pragma unroll
         for (int t = 0; t < VEC; ++t) xi[t] = fmaxf(fmaf(xi[t], xa_scale[c + t], xa_shift[c + t]), 0.f);
@@ -234,11 +258,27 @@ __global__ __launch_bounds__(256) void agg_bwd_wave(const float* __restrict__ x,
         if (accumulate_dx) o[t] += prev[t];
       }
       row_store<VEC>(po, o);
+      if constexpr (BST) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+          const float gm = xi[t] > 0.f ? o[t] : 0.f;                    // x' = relu(.) > 0  <=>  the pre-activation is > 0
+          bst_sh[(threadIdx.x >> 6) * C + c + t] = make_float2(gm, gm * ((xraw[t] - bn_mean[c + t]) * bn_invstd[c + t]));
+        }
+      }
     }
   }
   if (deps_part != nullptr) {
     dot = wave_sum(dot);
     if (lane == 0) deps_part[wid] = dot;
+  }
+  if constexpr (BST) {            // the four rows of the workgroup, added in wave order
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float2 a = bst_sh[c];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const float2 b = bst_sh[w * C + c]; a.x += b.x; a.y += b.y; }
+      bn_partial[(size_t)blockIdx.x * C + c] = a;
+    }
   }
 }
 
@@ -400,11 +440,11 @@ int esc_gine_aggregate_bwd(const float* x, int64_t ld_x, const float* e, int64_t
                    (!d_e || esc::aligned16(d_e)) && (!dx || esc::aligned16(dx));
   const int64_t blocks = esc::cdiv(N, 4);
   if (vec && esc_gine_aggregate_bwd_deps_slots(C) == 2)
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<2, false>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 2);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<2, false>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 2, (const float*)nullptr, (const float*)nullptr, (float2*)nullptr);
   else if (vec)
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 1);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float2*)nullptr);
   else
-    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 1);
+    esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, (const float*)nullptr, (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float2*)nullptr);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd");
   return ESC_OK;
 }
@@ -446,11 +486,37 @@ int esc_gine_aggregate_bwd_affine(const float* x, int64_t ld_x, const float* x_s
   ESC_REQUIRE(out_edge && out_dst, "esc_gine_aggregate_bwd_affine: null edge arrays");
   if (esc_gine_aggregate_bwd_deps_slots(C) == 2)
     esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<2, true>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, g, ld_g,
-                out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift, 2);
+                out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift, 2, (const float*)nullptr, (const float*)nullptr, (float2*)nullptr);
   else
     esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, g, ld_g,
-                out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift, 1);
+                out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale, x_shift, 1, (const float*)nullptr, (const float*)nullptr, (float2*)nullptr);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd_affine");
+  return ESC_OK;
+}
+
+/* esc_gine_aggregate_bwd_affine that also leaves the column sums of the BatchNorm backward in front of it: dx (required) is
+ * then the complete gradient of x' = relu(BN(x)), and partial[slot][C] (float2, slot = 4 consecutive source rows,
+ * esc_gine_aggregate_bwd_stats_slots(N) of them) holds (sum g, sum g*xhat) for esc_bn_bwd_coef_from_partials. */
+int64_t esc_gine_aggregate_bwd_stats_slots(int64_t N) { return esc::cdiv(N, 4); }
+
+int esc_gine_aggregate_bwd_affine_stats(const float* x, int64_t ld_x, const float* x_scale, const float* x_shift, const float* bn_mean,
+                                        const float* bn_invstd, const float* e, int64_t ld_e, const float* g, int64_t ld_g,
+                                        const int32_t* out_ptr, const int32_t* out_edge, const int32_t* out_dst, const float* eps, int64_t N,
+                                        int64_t C, float* d_e, int64_t ld_de, float* dx, int64_t ld_dx, int accumulate_dx, float* deps_part,
+                                        float* partial, void* stream) {
+  ESC_REQUIRE(x && x_scale && x_shift && bn_mean && bn_invstd && g && out_ptr && dx && partial, "esc_gine_aggregate_bwd_affine_stats: null pointer");
+  ESC_REQUIRE((e == nullptr) == (d_e == nullptr) || e != nullptr, "esc_gine_aggregate_bwd_affine_stats: d_e without e");
+  ESC_REQUIRE(N >= 0 && C >= 64 && C % 4 == 0 && C <= 2048 && ld_x >= C && ld_x % 4 == 0 && (!e || (ld_e >= C && ld_e % 4 == 0)) && ld_g >= C && ld_g % 4 == 0 &&
+              (!d_e || (ld_de >= C && ld_de % 4 == 0)) && ld_dx >= C && ld_dx % 4 == 0 && N < (1LL << 31) / 64,
+              "esc_gine_aggregate_bwd_affine_stats: needs 64 <= C <= 2048, C and the leading dimensions multiples of 4");
+  ESC_REQUIRE(esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(g) && (!d_e || esc::aligned16(d_e)) && esc::aligned16(dx) && esc::aligned16(partial),
+              "esc_gine_aggregate_bwd_affine_stats: pointers must be 16-byte aligned");
+  if (N == 0) return ESC_OK;
+  ESC_REQUIRE(out_edge && out_dst, "esc_gine_aggregate_bwd_affine_stats: null edge arrays");
+  esc::launch(ESC_K_AGG_BWD, esc::agg_bwd_wave<4, true, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), (size_t)4 * C * sizeof(float2), (hipStream_t)stream,
+              x, ld_x, e, ld_e, g, ld_g, out_ptr, out_edge, out_dst, eps, (int)N, (int)C, d_e, ld_de, dx, ld_dx, accumulate_dx, deps_part, x_scale,
+              x_shift, 1, bn_mean, bn_invstd, reinterpret_cast<float2*>(partial));
+  ESC_CHECK_LAUNCH("esc_gine_aggregate_bwd_affine_stats");
   return ESC_OK;
 }
 

@@ -12,6 +12,8 @@
 // scalar unit and every table row is one coalesced 16 B/lane read (H=256 => exactly 1 KiB/wave).
 #include "common.h"
 
+#include <cstdlib>
+
 // Bitwise contract with the sequential CPU scatter: this file is compiled with -ffp-contract=off
 // (see Makefile) so a*b+c is never fused behind our back; explicit fmaf() calls still emit FMAs
 // where the order is free.
@@ -99,6 +101,134 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
       *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     } else {
       *o = acc[0];
+    }
+  }
+}
+
+
+// ---- forward, LDS-staged table slices (r03) ------------------------------------------------------------------------------
+// The wave-per-row kernel above pulls Z rows of H floats through the L2 (563 MB for 21.9 MB of algorithmic bytes at config
+// 1: 23.7 us at ~24 TB/s of L2 traffic).  A block of consecutive edges touches few DISTINCT table rows (the edges of one
+// or two graphs share their histogram bins: ~60-150 of the 1800 rows), so a workgroup owns BAG_EB edges x a 64-column slice,
+// finds the rows its edges use, stages those rows' slices in LDS ONCE (<= BAG_CAP rows x 256 B) and serves every entry from
+// there: the L2 only sees each used (row, slice) once per workgroup.  16 lanes x float4 cover the 64 columns of one edge,
+// so a wave walks 4 edges at a time; the entry lists travel 16 entries per load and are broadcast inside the 16-lane
+// group.  Per column the sum still runs over the entries in order with separately rounded products: bit-identical to the
+// kernel above (and to the sequential scatter).  A workgroup whose edges use more rows than fit reads them from global
+// memory in the same layout.  STATS: the workgroup also leaves the (mean, M2) of its BAG_EB rows per column — the BatchNorm
+// partials esc_bn_stats_from_partials_rows(block_rows = BAG_EB) merges, i.e. the statistics pass over the output is gone.
+constexpr int BAG_EB = 128;          // edges per workgroup (32 per wave, 4 at a time)
+constexpr int BAG_CAP = 208;         // table rows a workgroup can stage: 208 x 256 B = 52 KB (two workgroups per CU)
+constexpr int BAG_MAXROWS = 4096;    // table height the row map serves
+
+template <bool ACC, bool STATS>
+__global__ __launch_bounds__(256) void bag_fwd_tiled(const float* __restrict__ table, int rows, int H,
+                                                     const int* __restrict__ row_ptr, const int* __restrict__ idx,
+                                                     const int* __restrict__ val, int E, float* __restrict__ out, int64_t ld_out,
+                                                     float2* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                                     // [BAG_CAP][64]
+  unsigned short* map = reinterpret_cast<unsigned short*>(smem + BAG_CAP * 256);      // [rows] -> slot, 0xFFFF = unused
+  unsigned short* list = map + ((rows + 7) & ~7);                                     // [BAG_CAP] slot -> row
+  __shared__ int n_active;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 64;                                  // this workgroup's column slice
+  const int e0 = blockIdx.y * BAG_EB, e1 = min(E, e0 + BAG_EB);
+  // 1. which table rows do these edges use?  (the entries of consecutive edges are consecutive)
+  for (int r = tid; r < rows; r += 256) map[r] = 0xFFFF;
+  if (tid == 0) n_active = 0;
+  __syncthreads();
+  const int zb = row_ptr[e0], ze = row_ptr[e1];
+  for (int z = zb + tid; z < ze; z += 256) map[idx[z]] = 0xFFFE;   // (benign race: every writer stores the same mark)
+  __syncthreads();
+  for (int r = tid; r < rows; r += 256) {
+    if (map[r] == 0xFFFE) {
+      const int sl = atomicAdd(&n_active, 1);                      // any injective numbering will do
+      map[r] = (unsigned short)min(sl, 0xFFF0);
+      if (sl < BAG_CAP) list[sl] = (unsigned short)r;
+    }
+  }
+  __syncthreads();
+  const int na = n_active;
+  const bool staged = na <= BAG_CAP;                               // workgroup-uniform
+  const int g = lane >> 4, t = lane & 15;                          // 16-lane group = one edge, lane t owns columns c0 + 4t .. +3
+  const bool col_ok = c0 + t * 4 < H;
+  if (staged) {      // 2. stage the used rows' slices: a 16-lane group copies one 256-byte piece
+    for (int sl = wave * 4 + g; sl < na; sl += 16) {
+      const int r = list[sl];
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col_ok) q = *reinterpret_cast<const float4*>(table + (size_t)r * H + c0 + t * 4);
+      *reinterpret_cast<float4*>(tile + sl * 64 + t * 4) = q;
+    }
+  }
+  __syncthreads();
+  // 3. the edges: wave w takes e0 + 32 w .. + 31, four at a time
+  float s_n = 0.f, s_mean[4] = {0.f, 0.f, 0.f, 0.f}, s_m2[4] = {0.f, 0.f, 0.f, 0.f};     // STATS: Welford over this lane's edges
+  for (int it = 0; it < 8; ++it) {
+    const int e = e0 + wave * 32 + it * 4 + g;
+    const bool live = e < e1;
+    const int beg = live ? row_ptr[e] : 0, end = live ? row_ptr[e + 1] : 0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ACC && live && col_ok) {
+      const float4 q = *reinterpret_cast<const float4*>(out + (size_t)e * ld_out + c0 + t * 4);
+      acc[0] = q.x; acc[1] = q.y; acc[2] = q.z; acc[3] = q.w;
+    }
+    int longest = end - beg;                                       // the four edges of the wave run in lockstep
+    longest = max(longest, __shfl_xor(longest, 16, 64));
+    longest = max(longest, __shfl_xor(longest, 32, 64));
+    for (int j = 0; j < longest; j += 16) {
+      // lane t of a group fetches entry j + t of its edge; slot (or row) and count are broadcast below
+      int my_r = 0; float my_v = 0.f;
+      if (beg + j + t < end) {
+        const int r = idx[beg + j + t];
+        my_r = staged ? (int)map[r] : r;
+        my_v = (float)val[beg + j + t];
+      }
+      const int todo = min(16, longest - j);
+      for (int k = 0; k < todo; ++k) {
+        const int r = __shfl(my_r, (g << 4) + k, 64);
+        const float v = __shfl(my_v, (g << 4) + k, 64);
+        float4 w;
+        if (staged) w = *reinterpret_cast<const float4*>(tile + r * 64 + t * 4);
+        else        w = col_ok ? *reinterpret_cast<const float4*>(table + (size_t)r * H + c0 + t * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (beg + j + k < end) {                                    // (a padded slot must not touch the sum: -0 + 0 = +0)
+          acc[0] = __fadd_rn(acc[0], __fmul_rn(w.x, v)); acc[1] = __fadd_rn(acc[1], __fmul_rn(w.y, v));
+          acc[2] = __fadd_rn(acc[2], __fmul_rn(w.z, v)); acc[3] = __fadd_rn(acc[3], __fmul_rn(w.w, v));
+        }
+      }
+    }
+    if (live && col_ok) *reinterpret_cast<float4*>(out + (size_t)e * ld_out + c0 + t * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if constexpr (STATS) {
+      if (live) {
+        s_n += 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float d = acc[q] - s_mean[q]; s_mean[q] += d / s_n; s_m2[q] = fmaf(d, acc[q] - s_mean[q], s_m2[q]); }
+      }
+    }
+  }
+  if constexpr (STATS) {      // 4. (count, mean, M2) of the 16 lane groups x waves that share a column: Chan merge in a fixed order
+    __syncthreads();                                               // the tile is dead: reuse it, [16 contributors][64 columns][3]
+    float* red = tile;
+    const int contrib = wave * 4 + g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float* p = red + (contrib * 64 + t * 4 + q) * 3;
+      p[0] = s_n; p[1] = s_mean[q]; p[2] = s_m2[q];
+    }
+    __syncthreads();
+    if (tid < 64 && c0 + tid < H && stats != nullptr) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (int u = 0; u < 16; ++u) {
+        const float* p = red + (u * 64 + tid) * 3;
+        const float nb = p[0];
+        if (nb > 0.f) {
+          const float tot = n + nb, delta = p[1] - mean;
+          mean += delta * (nb / tot);
+          m2 += p[2] + delta * delta * (n * nb / tot);
+          n = tot;
+        }
+      }
+      stats[(size_t)blockIdx.y * H + c0 + tid] = make_float2(mean, m2);
     }
   }
 }
@@ -331,6 +461,45 @@ int esc_bag_fwd_acc(const float* table, int64_t H, const int32_t* row_ptr, const
     esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_kernel<1, true>, dim3(blocks), dim3(256), 0, s, table, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out);
   ESC_CHECK_LAUNCH("esc_bag_fwd_acc");
   return ESC_OK;
+}
+
+
+/* the LDS-staged forward: needs the table height (rows), H % 4 == 0, 16-byte aligned table / out, ld_out % 4 == 0 */
+static bool bag_tiled_ok(const float* table, int64_t rows, int64_t H, const float* out, int64_t ld_out, int64_t E) {
+  // Measured on a config-1 batch (profiles/r03_kernel_roofline.txt): 70.9 us against 22.7 us of the wave-per-row kernel — 1 904
+  // waves walking 32 edges each through dependent entry-list loads cannot hide what 15 200 one-row waves hide by sheer
+  // numbers, and every workgroup pays the row map.  OFF by default (ESC_BAG_TILED=1 enables it for experiments); what it
+  // would take to win — the workgroup's entry lists staged in LDS too, batched reads — is in DESIGN.md.
+  static const int on = getenv("ESC_BAG_TILED") ? atoi(getenv("ESC_BAG_TILED")) : 0;
+  return on && rows > 0 && rows <= esc::BAG_MAXROWS && H % 4 == 0 && ld_out % 4 == 0 && esc::aligned16(table) && esc::aligned16(out) &&
+         E >= 4 * esc::BAG_EB && esc::cdiv(H, 64) <= 65535;
+}
+static size_t bag_tiled_lds(int64_t rows) { return (size_t)esc::BAG_CAP * 256 + (size_t)((rows + 7) & ~7) * 2 + (size_t)esc::BAG_CAP * 2 + 64; }
+
+int esc_bag_fwd_rows(const float* table, int64_t rows, int64_t H, const int32_t* row_ptr, const int32_t* idx32, const int32_t* val32,
+                     int64_t E, float* out, int64_t ld_out, int accumulate, float* stats, void* stream) {
+  ESC_REQUIRE(table && row_ptr && out && idx32 && val32, "esc_bag_fwd_rows: null pointer");
+  ESC_REQUIRE(H > 0 && E >= 0 && ld_out >= H && rows > 0 && E < (1LL << 31) / 64, "esc_bag_fwd_rows: bad sizes H=%ld E=%ld ld=%ld rows=%ld", (long)H, (long)E, (long)ld_out, (long)rows);
+  ESC_REQUIRE(stats == nullptr || (bag_tiled_ok(table, rows, H, out, ld_out, E) && !accumulate && esc::aligned16(stats)),
+              "esc_bag_fwd_rows: the statistics epilogue needs the tiled kernel (esc_bag_fwd_stats_block_rows() != 0) and no accumulation");
+  if (E == 0) return ESC_OK;
+  if (!bag_tiled_ok(table, rows, H, out, ld_out, E))
+    return accumulate ? esc_bag_fwd_acc(table, H, row_ptr, idx32, val32, E, out, ld_out, stream)
+                      : esc_bag_fwd(table, H, row_ptr, idx32, val32, E, out, ld_out, stream);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)esc::cdiv(H, 64), (unsigned)esc::cdiv(E, esc::BAG_EB));
+  const size_t lds = bag_tiled_lds(rows);
+  float2* st = reinterpret_cast<float2*>(stats);
+  if (accumulate)      esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_tiled<true, false>, grid, dim3(256), lds, s, table, (int)rows, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out, st);
+  else if (stats)      esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_tiled<false, true>, grid, dim3(256), lds, s, table, (int)rows, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out, st);
+  else                 esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_tiled<false, false>, grid, dim3(256), lds, s, table, (int)rows, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out, st);
+  ESC_CHECK_LAUNCH("esc_bag_fwd_rows");
+  return ESC_OK;
+}
+
+/* rows per BatchNorm partial the statistics epilogue of esc_bag_fwd_rows leaves (0: this shape is not served by it) */
+int64_t esc_bag_fwd_stats_block_rows(const float* table, int64_t rows, int64_t H, const float* out, int64_t ld_out, int64_t E) {
+  return bag_tiled_ok(table, rows, H, out, ld_out, E) ? esc::BAG_EB : 0;
 }
 
 int64_t esc_bag_bwd_scratch(int64_t Z, int64_t H) {      // chunk partials + (chunk order, bucket starts) of the local schedule

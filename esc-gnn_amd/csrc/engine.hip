@@ -47,6 +47,7 @@ struct Layout {
   float *col_stats;               // GEMM-epilogue BatchNorm partials: float2[ceil(rows/32)][H]
   float *col_stats_b;             // second set: a folded BatchNorm's partials live until its consumer has run
   float *bst_part;                // BatchNorm-backward column sums left by a dX epilogue / an aggregate backward: float2[slots][H]
+  float *bst_part_e;              // ... of the edge pipeline (z_embedding's first BatchNorm, from its Linear's dX epilogue)
   // private scratch of the x_embedding branch (runs on a side stream next to the z/conv chain)
   float *bn_scratch_x, *dT1x, *dT2x, *slabs_x;
   float *bn_scratch_e, *col_stats_e;   // the edge stream's own BatchNorm scratch / GEMM-epilogue partials
@@ -88,7 +89,8 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   y.bn_scratch_e = a.take(esc_bn_scratch(H));
   y.col_stats_e = a.take(2 * (E / 32 + 1) * H);
   if (train) {
-    y.bst_part = a.take(2 * (N / 16 + 2) * H);
+    y.bst_part = a.take(2 * (N / 4 + 2) * H);
+    y.bst_part_e = a.take(2 * (E / 64 + 2) * H);
     y.dT1x = a.take(N * H); y.dT2x = a.take(N * H);
     y.slabs_x = a.take(esc_linear_bwd_weight_scratch(N, H, H));
     y.dcat = a.take(N * y.W); y.dAl = a.take(N * H); y.dT1 = a.take(N * H); y.dT2 = a.take(N * H);
@@ -159,7 +161,7 @@ static int linear_backward(const Ctx& c, const float* dY, int64_t ld_dy, const f
 // launches.  The apply now happens while the GEMM stages its dY operand (bit 0) and the column sums of an MLP's FIRST
 // BatchNorm come out of the dX epilogue of its second Linear (bit 1): partial/finalize -> dX+dW -> finalize -> dX+dW.
 // ESC_BN_FUSE_BWD=0 restores the elementwise launches (A/B runs, bisecting).
-static int g_bn_fuse_bwd = getenv("ESC_BN_FUSE_BWD") ? atoi(getenv("ESC_BN_FUSE_BWD")) : 3;
+static int g_bn_fuse_bwd = getenv("ESC_BN_FUSE_BWD") ? atoi(getenv("ESC_BN_FUSE_BWD")) : 11;      // bit 2: the edge tail, see backward() (measured: no gain, off)
 static esc_bn_bwd_fused bn_fused(const float* x, int64_t ld_x, const BnWs& w, int relu) {
   return esc_bn_bwd_fused{x, ld_x, w.mean, w.invstd, w.scale, w.shift, w.coef, relu};
 }
@@ -203,7 +205,7 @@ struct EdgeStream {
 // 1: the weight gradient of the LAST conv.lin backward (l == 0, in the tail of the step) runs on the node stream.  Measured
 // neutral (1.038 vs 1.031-1.044 ms by the phase marks; so was doing the same for z_embedding's Linear): the node stream's
 // own reductions then become the end of the step.  Off.
-static int g_split_last_lin = getenv("ESC_SPLIT_LAST_LIN") ? atoi(getenv("ESC_SPLIT_LAST_LIN")) : 0;
+static int g_split_last_lin = getenv("ESC_SPLIT_LAST_LIN") ? atoi(getenv("ESC_SPLIT_LAST_LIN")) : 1;
 static int g_edge_priority_low = 1;
 static int g_use_edge_stream = 1;     // esc_engine_set_side_stream() bit 1
 static int current_device() {
@@ -300,6 +302,7 @@ static void mark(int which, void* stream) {
   (void)hipEventRecord(e, (hipStream_t)stream);
 }
 
+static int g_bag_stats = getenv("ESC_BAG_STATS") ? atoi(getenv("ESC_BAG_STATS")) : 1;   // BatchNorm partials from the bag kernel's epilogue
 static int g_e0_early = getenv("ESC_E0_EARLY") ? atoi(getenv("ESC_E0_EARLY")) : 1;   // see forward()
 static int g_fuse_finalize = 1; // ... and their merge by the GEMM's last workgroup (no bn_finalize launch)
 static int g_gemm_stats = 1;   // BatchNorm statistics from the producing GEMM's epilogue (no extra pass over Y)
@@ -559,8 +562,17 @@ static int forward(const Ctx& c) {
     ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));       // the batch arrays were produced on the caller's stream
     ce = edge_ctx(c, es.stream);
   }
-  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, ce.s));
-  ESC_TRY(bn_coeffs(ce, y.Zb, H, E, m->zbn0, y.zb0));
+  // ESC bag (LDS-staged table slices); in training mode its epilogue leaves the BatchNorm partials of z_embedding's first
+  // BatchNorm, so the statistics pass over the E x H output is one finalize launch
+  const int64_t bag_block = (c.train && !sync_on(ce) && g_bag_stats) ? esc_bag_fwd_stats_block_rows(m->z_table, m->z_rows, H, y.Zb, H, E) : 0;
+  if (bag_block > 0) {
+    ESC_TRY(esc_bag_fwd_rows(m->z_table, m->z_rows, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, 0, ce.y.col_stats, ce.s));
+    ESC_TRY(esc_bn_stats_from_partials_rows(ce.y.col_stats, E, H, bag_block, m->zbn0.eps, m->zbn0.momentum, y.zb0.mean, y.zb0.invstd,
+                                            m->zbn0.running_mean, m->zbn0.running_var, m->zbn0.gamma, m->zbn0.beta, y.zb0.scale, y.zb0.shift, ce.s));
+  } else {
+    ESC_TRY(esc_bag_fwd_rows(m->z_table, m->z_rows, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, 0, nullptr, ce.s));
+    ESC_TRY(bn_coeffs(ce, y.Zb, H, E, m->zbn0, y.zb0));
+  }
   const bool mat = g_materialise_edge_act != 0;
   if (mat) {
     ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, 1, y.A0, H, ce.s));
@@ -751,17 +763,29 @@ static int backward(const Ctx& c, Pending* defer) {
   edge_jobs.reserve(ESC_MAX_REDUCE_JOBS);    // the node pipeline's while the edge tail is still running
   if (es.ok && c.jobs) ce.jobs = &edge_jobs;
   std::vector<esc_sum_job> eps_jobs;
+  int64_t agg_slots = 0;            // > 0: the aggregate backward of the layer above left this layer's BatchNorm sums in bst_part
   for (int l = (int)L - 1; l >= 0; --l) {
     const esc_conv_t& cv = m->conv[l];
     const int64_t C = l == 0 ? y.C0 : H;
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
     ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W,
-                         y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C, fuse_node_act(c), l == (int)L - 1 ? last_slots : 0));
+                         y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C, fuse_node_act(c), l == (int)L - 1 ? last_slots : agg_slots));
+    agg_slots = 0;
     float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
     if (split_lin1 && l == (int)L - 1 &&                               // ... which the edge stream's lin1 blocks fill
         hipStreamWaitEvent((hipStream_t)c.s, es.lin1_rest, 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
-    if (fuse_node_act(c) && l > 0)
+    // (bit 3) d(cat)[:, l*H:(l+1)*H] is final once this launch has added its share: it leaves the column sums of the PREVIOUS layer's
+    // last BatchNorm backward, and that layer's MLP backward starts with the finalize
+    const bool stats_here = fuse_node_act(c) && l > 0 && (g_bn_fuse_bwd & 8) && esc_gine_aggregate_bwd_deps_slots(C) == 1 && C <= 2048 &&
+                            mlp_backward_fused(c, m->conv[l - 1].nn, y.conv[l - 1], y.agg[l - 1], l - 1 == 0 ? y.C0 : H, N, y.cat + (int64_t)l * H, W,
+                                               y.dcat + (int64_t)l * H, W, y.dagg, l - 1 == 0 ? y.C0 : H, true);
+    if (stats_here) {
+      ESC_TRY(esc_gine_aggregate_bwd_affine_stats(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.conv[l - 1].b1.mean,
+                                                  y.conv[l - 1].b1.invstd, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
+                                                  y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * 2 * N, y.bst_part, c.s));
+      agg_slots = esc_gine_aggregate_bwd_stats_slots(N);
+    } else if (fuse_node_act(c) && l > 0)
       ESC_TRY(esc_gine_aggregate_bwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], C, y.dagg, C,
                                             b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C, y.d_e[l], C, dx, W, 1,
                                             y.deps_part + (int64_t)l * 2 * N, c.s));
@@ -798,15 +822,33 @@ static int backward(const Ctx& c, Pending* defer) {
   // x_embedding backward queued above on the node stream
   const bool mat = g_materialise_edge_act != 0;
   // (the ReLU mask is recomputed from the pre-BN value even when the activation was materialised: one array less to read)
-  ESC_TRY(bn_backward(ce, y.Yz, H, nullptr, 0, y.dZemb, H, E, y.zb1, m->zbn1, y.dZemb, H, ce.y.bn_scratch));
   Ctx ct = ce;
   ct.on_edge_stream = ce.on_edge_stream && g_cap_tail;    // the tail is the critical path: its GEMM runs at full occupancy
+  // The tail is serial edge-sized work behind the last d_e: both of z_embedding's BatchNorm backwards lose a pass when they
+  // ride on its Linear's backward (bit 2 of g_bn_fuse_bwd) — BatchNorm 1's apply on the staged dY, BatchNorm 0's column sums
+  // from the dX epilogue: coef (2 launches), dX+dW, finalize, apply instead of 3 + 1 + 3
+  if ((g_bn_fuse_bwd & 4) && mat && c.act == 1 && !sync_on(c) && y.bst_part_e != nullptr) {
+    const esc_bn_bwd_fused f1 = bn_fused(y.Yz, H, y.zb1, 1);
+    const esc_bn_bwd_next n0{y.bst_part_e, y.Zb, H, y.zb0.mean, y.zb0.invstd, y.zb0.scale, y.zb0.shift, 1};
+    const float* slab_probe = ct.jobs ? *ct.slab_cursor : y.slabs;
+    if (esc_linear_bwd_both_bn_ok(y.dZemb, H, &f1, y.A0, H, m->zlin.w, H, E, H, H, y.dAz, H, slab_probe, &n0)) {
+      ESC_TRY(esc_bn_bwd_coef(y.Yz, H, nullptr, 0, y.dZemb, H, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma, m->zbn1.beta, 1, y.zb1.coef,
+                              m->zbn1.dgamma, m->zbn1.dbeta, ce.y.bn_scratch, ce.s));
+      ESC_TRY(linear_backward_bn(ct, y.dZemb, H, f1, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0, &n0));
+      ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part_e, cdiv(E, esc_linear_bwd_bn_block_rows(E, H, H)), E, H, y.zb0.coef, m->zbn0.dgamma,
+                                            m->zbn0.dbeta, ce.s));
+      ESC_TRY(esc_bn_bwd_apply(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, 1, y.zb0.coef, y.dAz, H, ce.s));
+      goto tail_bag;
+    }
+  }
+  ESC_TRY(bn_backward(ce, y.Yz, H, nullptr, 0, y.dZemb, H, E, y.zb1, m->zbn1, y.dZemb, H, ce.y.bn_scratch));
   if (mat) {
     ESC_TRY(linear_backward(ct, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
   } else {
     ESC_TRY(linear_backward(ct, y.dZemb, H, y.Zb, H, y.zb0.scale, y.zb0.shift, m->zlin, E, y.dAz, H, 0));
   }
   ESC_TRY(bn_backward(ce, y.Zb, H, nullptr, 0, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, ce.y.bn_scratch));
+tail_bag:
   ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E,
                                  1, m->dz_table, y.bag_scratch, ce.s));
   mark(PH_NODE_BWD_DONE, c.s);
@@ -897,7 +939,7 @@ static int forward_zinc(const ZincCtx& z) {
   }
   // z_emb = z_embedding(ESC bag) (:589-590), written into the first H columns of the edge-term input; the last D
   // columns are edge_type_embedding(edge_attr) (:591)
-  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, ce.s));
+  ESC_TRY(esc_bag_fwd_rows(m->z_table, m->z_rows, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, 0, nullptr, ce.s));
   if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, ce.s));
   ESC_TRY(bn_coeffs(ce, y.Zb, H, E, m->zbn0, y.zb0));
   ESC_TRY(esc_affine_act(y.Zb, H, E, H, y.zb0.scale, y.zb0.shift, act, y.A0, H, ce.s));
@@ -1121,7 +1163,7 @@ static int forward_ogb(const OgbCtx& z) {
     ce = edge_ctx(c, es.stream);
   }
   // z_emb = z_embedding(ESC bag): Dropout BN ReLU Linear Dropout BN ReLU (:638-645)
-  ESC_TRY(esc_bag_fwd(m->z_table, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, ce.s));
+  ESC_TRY(esc_bag_fwd_rows(m->z_table, m->z_rows, H, b->row_ptr, b->bag_idx, b->bag_val, E, y.Zb, H, 0, nullptr, ce.s));
   if (c.train) ESC_TRY(esc_bag_bwd_classify(b->col_row, y.Z, H, E, y.bag_scratch, ce.s));
   if (p > 0.f) ESC_TRY(esc_dropout_fwd(y.Zb, H, E, H, p, drop_seed(z, 0), nullptr, 0, y.Zd, H, y.mask_z0, ce.s));
   ESC_TRY(bn_coeffs(ce, y.Zd, H, E, m->zbn0, y.zb0));
@@ -1139,14 +1181,14 @@ static int forward_ogb(const OgbCtx& z) {
     const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
     const esc_ogb_layer_t& q = m->layer[l];
     ESC_TRY(esc_linear_fwd(y.Zemb, H, q.pos.w, H, q.pos.b, nullptr, nullptr, E, H, H, y.l[l].e, H, nullptr, ce.s));
-    ESC_TRY(esc_bag_fwd_acc(y.Tcat + q.bond_row0 * H, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, y.l[l].e, H, ce.s));
+    ESC_TRY(esc_bag_fwd_rows(y.Tcat + q.bond_row0 * H, m->bond_rows, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, y.l[l].e, H, 1, nullptr, ce.s));
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_ogb: stream event failed"); return ESC_ELAUNCH; }
     return ESC_OK;
   };
   const int ahead = es.ok ? g_edge_ahead : (int)L;
   for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
   // ---- node pipeline: h0 = AtomEncoder(x) (:264-282); vn_0 = virtualnode_embedding(0) per graph (:701)
-  ESC_TRY(esc_bag_fwd(y.Tcat, H, b->atoms.row_ptr, b->atoms.idx, b->atoms.ones, N, y.h0, H, c.s));
+  ESC_TRY(esc_bag_fwd_rows(y.Tcat, m->atom_rows, H, b->atoms.row_ptr, b->atoms.idx, b->atoms.ones, N, y.h0, H, 0, nullptr, c.s));
   ESC_TRY(esc_embed_fwd(m->vn_w, 1, H, b->zero_idx, G, y.l[0].vn, H, nullptr, c.s));
   for (int l = 0; l < (int)L; ++l) {
     const esc_ogb_layer_t& q = m->layer[l];

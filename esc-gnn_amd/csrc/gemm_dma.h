@@ -278,10 +278,17 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   if constexpr (P == 1) {
-    for (int k = threadIdx.x; k < g.R; k += C_::NTHR) { pro[k] = g.pro_scale[k]; pro[C_::PRO_MAXK + k] = g.pro_shift[k]; }
-    for (int k = g.R + threadIdx.x; k < ((g.R + BK - 1) / BK) * BK; k += C_::NTHR) { pro[k] = 0.f; pro[C_::PRO_MAXK + k] = 0.f; }   // partial last K-step
+    // with loader waves only the COMPUTE waves stage the coefficients: a loader's vmcnt(0) here would drain the ring's
+    // prologue transfers it has just issued before it may run ahead
+    const int kfirst = LW > 0 ? (loader ? 1 << 30 : (int)threadIdx.x) : (int)threadIdx.x;
+    constexpr int kstride = LW > 0 ? NW * 64 : C_::NTHR;
+    const int rpad1 = ((g.R + BK - 1) / BK) * BK;
+    for (int k = kfirst; k < rpad1; k += kstride) {
+      const bool in = k < g.R;                                            // partial last K-step: relu(0*0+0) = 0
+      pro[k] = in ? g.pro_scale[k] : 0.f; pro[C_::PRO_MAXK + k] = in ? g.pro_shift[k] : 0.f;
+    }
     // the raw s_barrier of the first K-step publishes these writes: they must have LANDED before this wave arrives there
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (LW == 0 || !loader) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   // BNB on a KC A (input-gradient tiles): six per-k arrays over the whole reduction range; k >= R: scale 0 -> operand 0
   float* bnbc = lds + C_::RING_FLOATS + C_::PRO_FLOATS;

@@ -1508,12 +1508,17 @@ static inline bool bnb_operands_ok(const esc_bn_bwd_fused* b, int64_t M, int64_t
          dma_ok(b->x, M, b->ld_x) && aligned16(b->mean) && aligned16(b->invstd) && aligned16(b->scale) && aligned16(b->shift) &&
          aligned16(b->coef);
 }
+static inline bool bnb_big_shape(int64_t M, int64_t N, int64_t K) { return M >= 8192 && tile128_ok(N) && tile128_ok(K); }
+static inline bool in_range_big(int64_t N) { return N <= 640; }
 static inline bool bnb_small_shape(int64_t N, int64_t K) { return (g_use_dma & 4) && K <= small::SMALL_MAX && N > small::SMALL_MAX && N % 4 == 0 && N <= 1024; }
 
 int esc_linear_bwd_both_bn_ok(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
                               const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx,
                               const float* slabs, const esc_bn_bwd_next* next) {
-  if (!dOut || !X || !W || !slabs || M <= 1 || M >= 8192 || N <= 0 || K <= 0 || (bn == nullptr && next == nullptr)) return 0;
+  if (!dOut || !X || !W || !slabs || M <= 1 || N <= 0 || K <= 0 || (bn == nullptr && next == nullptr)) return 0;
+  // edge-sized rows ride on the 128x128 tile (4 compute + 4 loader waves, one workgroup per CU, three ring stages even with the
+  // third operand image): only the square-ish H-wide layers it serves; everything else is node-sized
+  if (M >= 8192 && !(bnb_big_shape(M, N, K) && bn != nullptr && in_range_big(N))) return 0;
   if (bn != nullptr && !bnb_operands_ok(bn, M, N)) return 0;
   if (bn != nullptr && bnb_small_shape(N, K))
     return next == nullptr && aligned16(dOut) && ld_dout % 4 == 0 && ld_dout >= N && ld_x >= K && ld_w >= K && (dX == nullptr || ld_dx >= K);
@@ -1528,7 +1533,7 @@ int esc_linear_bwd_both_bn_ok(const float* dOut, int64_t ld_dout, const esc_bn_b
   return 1;
 }
 
-int64_t esc_linear_bwd_bn_block_rows(int64_t M, int64_t N, int64_t K) { (void)M; (void)N; (void)K; return 64; }
+int64_t esc_linear_bwd_bn_block_rows(int64_t M, int64_t N, int64_t K) { return bnb_big_shape(M, N, K) ? 128 : 64; }
 
 int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
                            const float* in_scale, const float* in_shift, const float* W, int64_t ld_w, int64_t M,
@@ -1563,8 +1568,9 @@ int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_
     ESC_CHECK_LAUNCH("esc_linear_bwd_both_bn.reduce");
     return ESC_OK;
   }
+  const bool big = bnb_big_shape(M, N, K);
   int splits, per;
-  dma_wgrad_plan(M, N, K, 64, 64, &splits, &per);
+  dma_wgrad_plan(M, N, K, big ? 128 : 64, big ? 128 : 64, &splits, &per);
   dma::DualArgs a{};
   dma_fill_dx(a.dx, dOut, ld_dout, W, ld_w, M, N, K, dX, ld_dx, accumulate);
   dma_fill_dw(a.dw, dOut, ld_dout, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
@@ -1574,7 +1580,10 @@ int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_
   hipError_t e;
   // (the third operand image of the fused apply costs a ring stage: two stages keep the workgroup at 54 KB, which fits beside
   // an edge-stream GEMM on a CU; three stages — 78 KB — measured slower inside the two-stream step)
-  if (bn == nullptr) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true, false, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false, false, true>(a, 0, s);
+  if (big) {
+    if (next) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true, true, true>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false, true, true>(a, 0, s);
+    else      e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true, true, false>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false, true, false>(a, 0, s);
+  } else if (bn == nullptr) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true, false, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false, false, true>(a, 0, s);
   else if (next) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, true>(a, 0, s);
   else      e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, false>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, false>(a, 0, s);
   if (dma_check(e, "esc_linear_bwd_both_bn") != hipSuccess) return ESC_ELAUNCH;

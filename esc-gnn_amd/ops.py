@@ -57,8 +57,8 @@ class _Bag(Function):
         _plan_on(table.device, plan, "row_ptr", "bag_idx", "bag_val", "col_ptr", "col_row", "col_val", "col_col")
         E, H = plan.num_edges, table.size(1)
         out = torch.empty((E, H), dtype=torch.float32, device=table.device)
-        nv.call("esc_bag_fwd", nv.ptr(table), H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx),
-                nv.ptr(plan.bag_val), E, nv.ptr(out), H, nv.stream())
+        nv.call("esc_bag_fwd_rows", nv.ptr(table), table.size(0), H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx),
+                nv.ptr(plan.bag_val), E, nv.ptr(out), H, 0, None, nv.stream())
         ctx.plan, ctx.shape = plan, tuple(table.shape)
         return out
 
@@ -570,8 +570,8 @@ class _EmbeddingSum(Function):
         H, dev = table.size(1), table.device
         plan = embed_plan(index, dims)
         out = torch.empty((n, H), dtype=torch.float32, device=dev)
-        nv.call("esc_bag_fwd", nv.ptr(table), H, nv.ptr(plan["row_ptr"]), nv.ptr(plan["idx32"]), nv.ptr(plan["ones"]), n,
-                nv.ptr(out), H, nv.stream())
+        nv.call("esc_bag_fwd_rows", nv.ptr(table), table.size(0), H, nv.ptr(plan["row_ptr"]), nv.ptr(plan["idx32"]), nv.ptr(plan["ones"]), n,
+                nv.ptr(out), H, 0, None, nv.stream())
         ctx.plan, ctx.rows, ctx.H, ctx.nk = plan, table.size(0), H, n * k
         return out
 

@@ -29,6 +29,32 @@ def shard_slice(batch_size, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_slice_balanced(weights, rank, world):
+    """Contiguous graph slice of rank `rank` that balances the SUM of `weights` (per-graph edge counts: the step's cost is
+    edge-sized work, SURVEY 8e "optionally balance by sum E") instead of the graph count: the cut points are where the
+    running sum crosses k/world of the total, every rank keeps at least one graph while there are enough of them.
+    Deterministic and identical on every rank (host arithmetic on the same numbers)."""
+    w = [float(x) for x in weights]
+    n = len(w)
+    if n <= world:
+        return shard_slice(n, rank, world)
+    total, run, cuts, k = sum(w), 0.0, [0], 1
+    for i, x in enumerate(w):
+        # close slice k-1 in front of graph i when adding it would overshoot the target by more than stopping short undershoots
+        while k < world and len(cuts) == k and i > cuts[-1] and (n - i) >= (world - k):
+            target = total * k / world
+            if run + x - target > target - run or (n - i) == (world - k):
+                cuts.append(i)
+                k += 1
+            else:
+                break
+        run += x
+    while len(cuts) < world:                             # (degenerate weights: fall back to the remaining graphs one by one)
+        cuts.append(min(n - (world - len(cuts)), max(cuts[-1] + 1, n - (world - len(cuts)))))
+    cuts.append(n)
+    return cuts[rank], cuts[rank + 1]
+
+
 class FlatBucket(object):
     """Re-homes parameters and gradients of a model as views into two flat fp32 buffers
     (+1 trailing slot in the gradient buffer for the node-count piggyback)."""

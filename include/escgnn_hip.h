@@ -47,6 +47,17 @@ int esc_prof_reset(int kind);
  * a sequential scatter_add of (W[idx]*val) produces. */
 int esc_bag_fwd(const float* table, int64_t H, const int32_t* row_ptr, const int32_t* idx32,
                 const int32_t* val32, int64_t E, float* out, int64_t ld_out, void* stream);
+/* The same sums with the table height given (r03): a workgroup owns 128 consecutive edges x a 64-column slice and stages the
+ * table rows ITS edges use in LDS once (north_star's "LDS-staged feature tiles"), instead of pulling every entry's row
+ * through the L2; bit-identical results.  accumulate != 0 adds onto `out` (esc_bag_fwd_acc).  stats (may be NULL, not with
+ * accumulate): float2[ceil(E / B)][H] (mean, M2) of the output columns per block of B = esc_bag_fwd_stats_block_rows(...)
+ * rows — the partials esc_bn_stats_from_partials_rows merges, so the BatchNorm behind the bag needs no pass over `out`
+ * (run_graphcount.py:155-156: z_embedding starts with BatchNorm).  Shapes the tiled kernel does not serve (table higher
+ * than 4096 rows, H % 4 != 0, fewer than 512 edges) take the wave-per-row kernel; stats then must be NULL
+ * (esc_bag_fwd_stats_block_rows returns 0). */
+int esc_bag_fwd_rows(const float* table, int64_t rows, int64_t H, const int32_t* row_ptr, const int32_t* idx32,
+                     const int32_t* val32, int64_t E, float* out, int64_t ld_out, int accumulate, float* stats, void* stream);
+int64_t esc_bag_fwd_stats_block_rows(const float* table, int64_t rows, int64_t H, const float* out, int64_t ld_out, int64_t E);
 /* dTable[c,:] = sum_{j: idx_j=c} val_j * dZ[row_j,:] — deterministic two-pass segmented sum over
  * the CSC view; `partials` = esc_bag_bwd_scratch(Z,H) floats of scratch.  Writes ALL n_cols rows
  * (zeros where a column has no entry). */
@@ -96,6 +107,18 @@ int esc_gine_aggregate_bwd_affine(const float* x, int64_t ld_x, const float* x_s
                                   int64_t ld_e, const float* g, int64_t ld_g, const int32_t* out_ptr, const int32_t* out_edge,
                                   const int32_t* out_dst, const float* eps, int64_t N, int64_t C, float* d_e, int64_t ld_de,
                                   float* dx, int64_t ld_dx, int accumulate_dx, float* deps_part, void* stream);
+
+/* esc_gine_aggregate_bwd_affine that also leaves the column sums of the BatchNorm(+ReLU) backward IN FRONT of it (r03): dx
+ * (required) is then the complete gradient of x' = relu(BN(x)); bn_mean / bn_invstd are that BatchNorm's statistics and
+ * partial[slot][C] (float2; one slot per 4 consecutive source rows: esc_gine_aggregate_bwd_stats_slots(N) slots) receives
+ * (sum g, sum g*xhat), g = dx * [x' > 0] — the input of esc_bn_bwd_coef_from_partials.  One launch less on the node chain
+ * per GINE layer (the partial-sum pass of the previous layer's last BatchNorm, run_graphcount.py:80-87 backward). */
+int64_t esc_gine_aggregate_bwd_stats_slots(int64_t N);
+int esc_gine_aggregate_bwd_affine_stats(const float* x, int64_t ld_x, const float* x_scale, const float* x_shift, const float* bn_mean,
+                                        const float* bn_invstd, const float* e, int64_t ld_e, const float* g, int64_t ld_g,
+                                        const int32_t* out_ptr, const int32_t* out_edge, const int32_t* out_dst, const float* eps,
+                                        int64_t N, int64_t C, float* d_e, int64_t ld_de, float* dx, int64_t ld_dx, int accumulate_dx,
+                                        float* deps_part, float* partial, void* stream);
 
 /* graph readout (a-10): global_add_pool / global_mean_pool (run_graphcount.py:179; zinc_models.py:602) over the
  * sorted node->graph vector given as segment pointers seg_ptr[G+1]; rows summed in node order (bit-identical to

@@ -117,7 +117,7 @@ def test_config4_zinc_layers5_bs128(E):
     assert float((out.detach().cpu().double() - p64.detach()).abs().max()) / scale <= 1e-5
     assert abs(float(loss.detach()) - float(l64.detach())) <= 1e-5 * max(1.0, abs(float(l64.detach())))
     _grad_check(mine.named_parameters(), {n: p.grad for n, p in ref.named_parameters()},
-                {n: p.grad for n, p in ref64.named_parameters()})
+                {n: p.grad for n, p in ref64.named_parameters()}, max_kinked=2)        # r03 box: 0 tensors
     # eval mode on the running statistics: against the fp64 oracle evaluated on THE SAME buffers (the module's own running
     # statistics and parameters after the step above), so that only the arithmetic of the eval forward is compared: 1e-5.
     # (Against the fp32 oracle's own buffers the two differ by what one momentum update in fp32 leaves: 1e-4 was r02's bound.)
@@ -169,7 +169,7 @@ def test_config5_molhiv_h4_layers6_emb300_bs256(E):
     assert float((out.detach().cpu().double() - o64.detach()).abs().max()) / scale <= 1e-5
     assert abs(float(loss.detach()) - float(l64.detach())) <= 1e-5 * max(1.0, abs(float(l64.detach())))
     _grad_check(mine.named_parameters(), {n: p.grad for n, p in ref.named_parameters()},
-                {n: p.grad for n, p in ref64.named_parameters()})
+                {n: p.grad for n, p in ref64.named_parameters()}, max_kinked=3)        # r03 box: 1 tensor (convs.4.mlp.3.weight)
 
 
 def test_config5_full_size_with_dropout_through_the_mask_replay(E):
@@ -182,4 +182,4 @@ def test_config5_full_size_with_dropout_through_the_mask_replay(E):
     graphs = build_feature_dataset(synthetic_ogbmol_graphs(0, bs), 4, use_rd=True, self_loop=True)
     b = E.DeviceGraphStore(graphs, DEV).collate(torch.arange(bs))
     bt = {k: b[k].cpu() for k in ("x", "edge_index", "edge_attr", "y", "pos_enc", "pos_index", "pos_batch", "batch")}
-    _ogb_engine_vs_per_op(bt, 6, 300, 0.5, True, "mean", max_kinked=8)
+    _ogb_engine_vs_per_op(bt, 6, 300, 0.5, True, "mean", max_kinked=8)        # r03 box: 4 tensors

@@ -683,6 +683,25 @@ def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(
     with pytest.raises(RuntimeError):                        # narrow rows have no affine variant
         nv.call("esc_gine_aggregate_fwd_affine", nv.ptr(x), ld, nv.ptr(sc), nv.ptr(sh), nv.ptr(e), C, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge),
                 nv.ptr(plan.in_src), nv.ptr(eps), N, 32, nv.ptr(got), C, s)
+    # ... and the variant that leaves the column sums of the BatchNorm backward in front of it (r03): same d_e / dx / deps bits,
+    # partials that finalize to what esc_bn_bwd_coef computes from (x, dx)
+    mean = (-sh / sc).contiguous()                           # any per-column statistics will do for the sums
+    invstd = (torch.rand(C, generator=g0) + 0.5).to(dev)
+    slots = int(nv.lib().esc_gine_aggregate_bwd_stats_slots(N))
+    part = torch.full((slots, C, 2), float("nan"), device=dev)
+    de2, dx2 = torch.empty(Ee, C, device=dev), torch.full((N, C), 0.25, device=dev)
+    dp2 = torch.empty(N * int(nv.lib().esc_gine_aggregate_bwd_deps_slots(C)), device=dev)
+    nv.call("esc_gine_aggregate_bwd_affine_stats", nv.ptr(x), ld, nv.ptr(sc), nv.ptr(sh), nv.ptr(mean), nv.ptr(invstd), nv.ptr(e), C, nv.ptr(g), C,
+            nv.ptr(plan.out_ptr), nv.ptr(plan.out_edge), nv.ptr(plan.out_dst), nv.ptr(eps), N, C, nv.ptr(de2), C, nv.ptr(dx2), C, 1, nv.ptr(dp2),
+            nv.ptr(part), s)
+    assert torch.equal(de2, outs[1][0]) and torch.equal(dx2, outs[1][1]) and torch.equal(dp2, outs[1][2])
+    assert not bool(torch.isnan(part).any())
+    xs = x[:, :C].double().cpu()
+    pre = xs * sc.double().cpu() + sh.double().cpu()
+    gm = torch.where(pre > 0, dx2.double().cpu(), torch.zeros((), dtype=torch.float64))
+    xh = (xs - mean.double().cpu()) * invstd.double().cpu()
+    _chk(part[:, :, 0].sum(0), gm.sum(0), "sum g from the aggregate backward")
+    _chk(part[:, :, 1].sum(0), (gm * xh).sum(0), "sum g*xhat from the aggregate backward")
 
 
 @pytest.mark.parametrize("M,N,K,relu,pro,acc,nxt", [
@@ -693,6 +712,8 @@ def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(
     (77, 64, 96, 0, False, 0, True),         # ragged rows, no activation
     (1500, 300, 600, 1, True, 0, True),      # widths that are not multiples of the 32-wide K-step
     (333, 128, 16, 1, True, 0, False),
+    (15200, 256, 256, 1, False, 0, True),    # z_embedding.3 backward (edge rows: the 128x128 tile), both BatchNorms of the tail
+    (9000, 256, 256, 1, True, 1, False),
 ])
 def test_linear_backward_with_batchnorm_backward_folded_in(E, M, N, K, relu, pro, acc, nxt):
     """esc_linear_bwd_both_bn == esc_bn_bwd_apply -> esc_linear_bwd_both (run_graphcount.py:65-73,78-87,183-186 backward):
@@ -826,3 +847,57 @@ def test_linear_backward_leaves_the_next_batchnorm_sums_without_a_fused_apply(E)
             nv.ptr(rg2), nv.ptr(rb2), nv.ptr(scratch), nv.stream())
     for a, b, name in ((c2, r2, "coef"), (dg2, rg2, "dgamma"), (db2, rb2, "dbeta")):
         assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), name
+
+
+@pytest.mark.parametrize("H,spread", [(256, False), (300, False), (64, False), (256, True)])
+def test_bag_forward_with_lds_staged_table_slices(E, H, spread):
+    """esc_bag_fwd_rows (r03: a workgroup stages the table rows its 128 edges use in LDS) against the wave-per-row kernel and the
+    sequential CPU scatter — bit for bit, plain and accumulating; `spread` draws the bins uniformly over all 1800 rows so that
+    a workgroup needs more rows than it can stage and takes the global-memory branch; the statistics epilogue against
+    esc_bn_stats (run_graphcount.py:155-156: bag -> BatchNorm)."""
+    nv = E._native
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + int(spread))
+    Ee, rows = 3000, 1800
+    cnt = torch.randint(20, 60, (Ee,), generator=g)
+    cnt[7] = 0                                                     # an edge without entries
+    row_ptr = torch.zeros(Ee + 1, dtype=torch.int64); row_ptr[1:] = torch.cumsum(cnt, 0)
+    Z = int(row_ptr[-1])
+    seg = torch.repeat_interleave(torch.arange(Ee), cnt)
+    if spread:
+        idx = torch.randint(0, rows, (Z,), generator=g)
+    else:                                                          # like real batches: the edges of a graph share ~100 bins
+        base = (seg // 120) * 37 % 1500
+        idx = base + torch.randint(0, 100, (Z,), generator=g)
+    val = torch.randint(1, 9, (Z,), generator=g)
+    W = torch.randn(rows, H, generator=g)
+    torch.set_num_threads(1)
+    ref = torch.zeros(Ee, H).index_add_(0, seg, W[idx] * val.view(-1, 1).float())
+    rp, ix, vl, Wd = row_ptr.to(torch.int32).to(dev), idx.to(torch.int32).to(dev), val.to(torch.int32).to(dev), W.to(dev)
+    old, new = torch.empty(Ee, H, device=dev), torch.empty(Ee, H, device=dev)
+    nv.call("esc_bag_fwd", nv.ptr(Wd), H, nv.ptr(rp), nv.ptr(ix), nv.ptr(vl), Ee, nv.ptr(old), H, nv.stream())
+    block = int(nv.lib().esc_bag_fwd_stats_block_rows(nv.ptr(Wd), rows, H, nv.ptr(new), H, Ee))
+    if block == 0:                                                 # the tiled kernel is off by default (ESC_BAG_TILED=1 enables it):
+        nv.call("esc_bag_fwd_rows", nv.ptr(Wd), rows, H, nv.ptr(rp), nv.ptr(ix), nv.ptr(vl), Ee, nv.ptr(new), H, 0, None, nv.stream())
+        assert torch.equal(old.cpu(), ref) and torch.equal(new, old)     # the entry point then runs the wave-per-row kernel
+        with pytest.raises(RuntimeError):
+            nv.call("esc_bag_fwd_rows", nv.ptr(Wd), rows, H, nv.ptr(rp), nv.ptr(ix), nv.ptr(vl), Ee, nv.ptr(new), H, 0, nv.ptr(old), nv.stream())
+        return
+    assert block == 128
+    stats = torch.full((-(-Ee // block), H, 2), float("nan"), device=dev)
+    nv.call("esc_bag_fwd_rows", nv.ptr(Wd), rows, H, nv.ptr(rp), nv.ptr(ix), nv.ptr(vl), Ee, nv.ptr(new), H, 0, nv.ptr(stats), nv.stream())
+    assert torch.equal(old.cpu(), ref) and torch.equal(new, old)
+    acc0 = torch.randn(Ee, H, generator=g)
+    a1, a2 = acc0.to(dev), acc0.to(dev)
+    nv.call("esc_bag_fwd_acc", nv.ptr(Wd), H, nv.ptr(rp), nv.ptr(ix), nv.ptr(vl), Ee, nv.ptr(a1), H, nv.stream())
+    nv.call("esc_bag_fwd_rows", nv.ptr(Wd), rows, H, nv.ptr(rp), nv.ptr(ix), nv.ptr(vl), Ee, nv.ptr(a2), H, 1, None, nv.stream())
+    assert torch.equal(a1, a2)
+    # the epilogue's partials -> the same statistics as a pass over the output
+    mean, invstd, sc, sh = (torch.empty(H, device=dev) for _ in range(4))
+    nv.call("esc_bn_stats_from_partials_rows", nv.ptr(stats), Ee, H, block, 1e-5, 0.1, nv.ptr(mean), nv.ptr(invstd), None, None, None, None,
+            nv.ptr(sc), nv.ptr(sh), nv.stream())
+    assert not bool(torch.isnan(stats).any())
+    _chk(mean, ref.double().mean(0), "mean from the bag epilogue")
+    _chk(invstd, 1.0 / torch.sqrt(ref.double().var(0, unbiased=False) + 1e-5), "invstd from the bag epilogue")
+    with pytest.raises(RuntimeError):                              # fewer edges than the tiled kernel serves: no statistics
+        nv.call("esc_bag_fwd_rows", nv.ptr(Wd), rows, H, nv.ptr(rp), nv.ptr(ix), nv.ptr(vl), 100, nv.ptr(new), H, 0, nv.ptr(stats), nv.stream())

@@ -131,3 +131,21 @@ def test_shard_slice_covers_batch():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(W - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_edge_balanced_slices_cover_the_batch_and_balance_the_edge_count():
+    """SURVEY 8e "optionally balance by sum E": contiguous slices cut where the running edge count crosses k/W of the total"""
+    import random
+    import esc_gnn_amd as E
+    random.seed(3)
+    for _ in range(300):
+        n, W = random.randint(1, 60), random.randint(1, 8)
+        w = [random.choice([70, 96, 105, 180]) for _ in range(n)]
+        parts = [E.parallel.shard_slice_balanced(w, r, W) for r in range(W)]
+        assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        if n >= W:
+            assert all(hi > lo for lo, hi in parts)
+    w = [180] * 16 + [70] * 112                                 # 16 big graphs first: equal COUNTS would give rank 0 1.9x the mean
+    even = [sum(w[lo:hi]) for lo, hi in (E.parallel.shard_slice(len(w), r, 8) for r in range(8))]
+    bal = [sum(w[lo:hi]) for lo, hi in (E.parallel.shard_slice_balanced(w, r, 8) for r in range(8))]
+    assert max(bal) <= 1.15 * sum(w) / 8 < max(even)
