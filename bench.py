@@ -325,8 +325,9 @@ def main():
         traffic = tj.get("traffic_bytes_per_launch")
         tsrc = ("committed PMC passes of this command (profiles/%s: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
                 "runs, FETCH x2 gfx950 correction, tools/parse_pmc.py) - NOT measured in this run" % os.path.basename(tpaths[-1]))
-    roofline = dict(kernel="esc::agg_fwd_wave<4, true> (GINE aggregate forward = the scatter-add, C=%d; the gathered rows get the previous "
-                           "layer's BatchNorm+ReLU applied as they are read)" % args.hidden,
+    split = "2, true> (two waves per destination row" if (args.hidden == 256 and os.environ.get("ESC_AGG_SPLIT", "2") == "2") else "4, true> (one wave per destination row"
+    roofline = dict(kernel="esc::agg_fwd_wave<%s; GINE aggregate forward = the scatter-add, C=%d; the gathered rows get the previous "
+                           "layer's BatchNorm+ReLU applied as they are read)" % (split, args.hidden),
                     bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None if traffic is None else int(traffic),
                     traffic_source=tsrc,

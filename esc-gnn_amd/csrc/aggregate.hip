@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
 // rows of exactly 256 floats (the hidden width of the reference, run_graphcount.py:465) may be split over two waves of 128
 // columns, 8 bytes per lane (see agg_fwd_wave).  Measured on a config-1 batch (profiles/r03_kernel_roofline.txt): forward
 // 7.2 -> 6.5 us with cold operands, 6.4 either way cache-resident: ON (ESC_AGG_SPLIT=1 switches it off); backward 11.8 -> 11.0
-// cold but 8.2 -> 9.3 with the operands the step has just produced: OFF (ESC_AGG_SPLIT_BWD=2 switches it on).
+// cold but 8.2 -> 9.3 with the operands the step has just produced: OFF (ESC_AGG_SPLIT_BWD=2 switches it on).  Non-temporal loads
+// of the once-streamed edge-term rows (so that they would not evict the gathered x rows from the L2) measured SLOWER
+// (cache-resident 6.4 -> 7.4 us, cold 6.5 -> 7.2) and were removed again.
 static int g_agg_split = getenv("ESC_AGG_SPLIT") ? atoi(getenv("ESC_AGG_SPLIT")) : 2;
 static int g_agg_split_bwd = getenv("ESC_AGG_SPLIT_BWD") ? atoi(getenv("ESC_AGG_SPLIT_BWD")) : 1;
 static inline int agg_split(int64_t C) { return (g_agg_split == 2 && C == 256) ? 2 : 1; }

@@ -1071,6 +1071,7 @@ struct OgbLayout {
   // backward
   float *dpooled, *dHa, *dHb, *dT, *dA1, *dagg, *dZemb, *dYz, *dA0, *dvn_a, *dvn_b, *dG1, *dG2, *dtmp, *poolG;
   float *deps_part, *bag_scratch, *emb_scratch, *emb_scratch_n, *slabs, *bn_scratch, *col_stats, *bn_scratch_e, *col_stats_e;
+  float *bst_part;                 // column sums of a node MLP's first BatchNorm backward, left by its second Linear's dX epilogue
   int64_t total;
 };
 
@@ -1112,6 +1113,7 @@ static OgbLayout plan_layout_ogb(const esc_ogb_gnn_t* m, int64_t N, int64_t E, i
   y.col_stats_e = a.take(2 * (E / 32 + 1) * H2);
   if (train) {
     y.dTcat = a.take(rows_total * H);
+    y.bst_part = a.take(2 * (N / 64 + 2) * H2);
     y.dpooled = a.take(G * H); y.dHa = a.take(N * H); y.dHb = a.take(N * H); y.dT = a.take(N * H);
     y.dA1 = a.take(N * H2); y.dagg = a.take(N * H);
     y.dZemb = a.take(E * H); y.dYz = a.take(E * H); y.dA0 = a.take(E * H);
@@ -1255,9 +1257,34 @@ static int backward_ogb(const OgbCtx& z) {
     const bool last = l == (int)L - 1;
     // h_{l+1} = dropout(hb) (+ hin)
     ESC_TRY(bn_backward_drop(last ? c0 : c, w.hc, H, dH, H, N, w.bn, q.bn, w.mask_h, p, 0, y.dT, H, y.bn_scratch));
-    if (g_ogb_prologue) ESC_TRY(linear_backward(c, y.dT, H, w.Y0, H2, w.b0.scale, w.b0.shift, q.lin1, N, y.dA1, H2, 0));
-    else                ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
-    ESC_TRY(bn_backward(c, w.Y0, H2, nullptr, 0, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));      // (ReLU mask from the pre-BatchNorm rows: A1 is not re-read)
+    // The hidden BatchNorm's backward loses its partial-sum pass (2H-wide rows: the most expensive of its three launches): the
+    // column sums come out of lin1's dX epilogue (esc_linear_bwd_both_bn with bn == NULL), then finalize + apply
+    bool hidden_done = false;
+    if (g_ogb_prologue && (g_bn_fuse_bwd & 2) && !sync_on(c) && y.bst_part != nullptr) {
+      const esc_bn_bwd_next n0{y.bst_part, w.Y0, H2, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, 1};
+      const float* slab_probe = c.jobs ? *c.slab_cursor : c.y.slabs;
+      if (esc_linear_bwd_both_bn_ok(y.dT, H, nullptr, w.Y0, H2, q.lin1.w, H2, N, H, H2, y.dA1, H2, slab_probe, &n0)) {
+        float* slabs = c.y.slabs;
+        esc_reduce_job* job = nullptr;
+        if (c.jobs) {
+          slabs = *c.slab_cursor;
+          *c.slab_cursor += (esc_linear_bwd_weight_scratch(N, H, H2) + 63) & ~63LL;
+          c.jobs->emplace_back();
+          job = &c.jobs->back();
+        }
+        ESC_TRY(esc_linear_bwd_both_bn(y.dT, H, nullptr, w.Y0, H2, w.b0.scale, w.b0.shift, q.lin1.w, H2, N, H, H2, y.dA1, H2, 0, q.lin1.dw, H2,
+                                       q.lin1.db, slabs, job, &n0, c.s));
+        ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, cdiv(N, esc_linear_bwd_bn_block_rows(N, H, H2)), N, H2, w.b0.coef, q.bn0.dgamma,
+                                              q.bn0.dbeta, c.s));
+        ESC_TRY(esc_bn_bwd_apply(w.Y0, H2, nullptr, 0, y.dA1, H2, N, H2, w.b0.mean, w.b0.invstd, q.bn0.gamma, q.bn0.beta, 1, w.b0.coef, y.dA1, H2, c.s));
+        hidden_done = true;
+      }
+    }
+    if (!hidden_done) {
+      if (g_ogb_prologue) ESC_TRY(linear_backward(c, y.dT, H, w.Y0, H2, w.b0.scale, w.b0.shift, q.lin1, N, y.dA1, H2, 0));
+      else                ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
+      ESC_TRY(bn_backward(c, w.Y0, H2, nullptr, 0, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));      // (ReLU mask from the pre-BatchNorm rows: A1 is not re-read)
+    }
     ESC_TRY(linear_backward(c, y.dA1, H2, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0));
     // virtual-node update of this layer: vn_{l+1} = dropout(mlp(add_pool(hin) + vn_l)) (+ vn_l)
     bool have_dhin = false;

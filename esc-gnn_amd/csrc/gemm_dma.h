@@ -109,6 +109,18 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// DMA piece geometry of one operand tile.  KC tile [T][BK]: 1-KiB pieces of 1024 / (4 BK) whole rows.  RM tile [BK][T]: a piece is
+// as many WHOLE rows of 4 T bytes as fit 1 KiB (T = 256, 128, 64, 32: the piece is full; T = 160 (r03: 300 / 600-wide layers):
+// one row of 640 bytes, 40 of the 64 lanes active — the rest are masked off, their LDS slots belong to the next piece).
+template <int T, int BK, bool RM> struct Pieces {
+  static constexpr int RB = RM ? T * 4 : BK * 4;              // bytes of a tile row in LDS
+  static constexpr int RPP = 1024 / RB;                       // rows per piece
+  static constexpr int BYTES = RPP * RB;                      // LDS bytes a piece covers
+  static constexpr int LANES = BYTES / 16;                    // active lanes
+  static constexpr int COUNT = (RM ? BK : T) / RPP;           // pieces per tile
+  static_assert(RB <= 1024 && RB % 16 == 0 && (RM ? BK : T) % RPP == 0, "tile rows must fit a DMA piece and tile it evenly");
+};
+
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
 struct Cfg {
   static constexpr int P = PRO & 3;                                     // operand prologue (see GArgs)
@@ -116,7 +128,8 @@ struct Cfg {
   static constexpr int NW = WM * WN, NWT = NW + LW, NTHR = NWT * 64, DW = LW > 0 ? LW : NW;
   static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, A2_FLOATS = BNB ? A_FLOATS : 0;   // A2: the BatchNorm input rows beside dOut
   static constexpr int STAGE_FLOATS = A_FLOATS + A2_FLOATS + B_FLOATS;
-  static constexpr int PA = A_FLOATS / 256, PB = B_FLOATS / 256;        // 1-KiB pieces per tile
+  using PcA = Pieces<BM, BK, A_RM>; using PcB = Pieces<BN, BK, B_RM>;
+  static constexpr int PA = PcA::COUNT, PB = PcB::COUNT;                // DMA pieces per tile
   static constexpr int PPWA = PA / DW, PPWB = PB / DW, PPW = PPWA * (BNB ? 2 : 1) + PPWB;
   static constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
   static constexpr int OUT_LD = BN + 4, OUT_FLOATS = BM * OUT_LD;       // epilogue staging image [BM][BN+4]
@@ -134,7 +147,7 @@ struct Cfg {
   static constexpr int C4 = BN / 4;                                     // float4 per output row of the tile
   static_assert(PA % DW == 0 && PB % DW == 0, "pieces must split evenly over the DMA waves");
   static_assert(MT >= 1 && NT >= 1 && STAGES >= 2 && STAGES <= 4, "bad tile");
-  static_assert(NTHR % C4 == 0, "a thread keeps one column quad through the epilogue");
+  static_assert(NTHR >= C4, "a thread keeps one column quad through the epilogue");
   static_assert(P == 0 || (PRO_A && !A_RM) || (P == 2 && B_RM), "prologue: per-k on a KC A, or per-column on an RM B");
   static_assert(!(BNB && PRO_A), "the BatchNorm backward and the affine prologue both transform A");
   static_assert(!BSTAT || (!A_RM && B_RM && !STATS), "BatchNorm-backward partials ride on the input-gradient tiles");
@@ -164,7 +177,7 @@ __device__ __forceinline__ void dma_offsets(int (&vo)[NP], int (&kc)[NP], int dw
   } else {
     constexpr int RB = T * 4, CPR = RB / 16, RPP = 1024 / RB;
     static_assert(RB <= 1024, "RM tile rows longer than one DMA piece are not supported");
-    const int prow = l / CPR, pc = l % CPR;
+    const int prow = l / CPR, pc = l % CPR;                  // (lanes >= RPP * CPR are masked off by the issuer)
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int row = (dw + DW * j) * RPP + prow;
@@ -222,8 +235,9 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   const unsigned lds_base = lds_addr(lds);
   int issued = 0;                                           // K-steps issued so far by this wave
   auto stage = [&](int buf) {
-    const unsigned a_dst = lds_base + (unsigned)(buf * C_::STAGE_FLOATS + dw * 256) * 4u;
-    const unsigned b_dst = a_dst + (C_::A_FLOATS + C_::A2_FLOATS) * 4u;
+    const unsigned a_dst0 = lds_base + (unsigned)(buf * C_::STAGE_FLOATS) * 4u;
+    const unsigned a_dst = a_dst0 + (unsigned)dw * (unsigned)C_::PcA::BYTES;
+    const unsigned b_dst = a_dst0 + (C_::A_FLOATS + C_::A2_FLOATS) * 4u + (unsigned)dw * (unsigned)C_::PcB::BYTES;
     const int k0 = red0 + issued * BK;                      // first reduction index of this K-step
     const int soff = k0 * 4;                                // KC operands: K offset (an SGPR offset is not range-checked)
     const bool tail = k0 + BK > red1;                       // wave-uniform: the partial last K-step of a KC operand
@@ -231,7 +245,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
     for (int j = 0; j < PPWA; ++j) {
       int vo = voa[j];
       if constexpr (!A_RM) { if (tail && k0 + kca[j] >= red1) vo = OOB; }
-      dma16(ra, a_dst + (unsigned)(DW * j) * 1024u, vo, A_RM ? 0 : soff);
+      if (C_::PcA::LANES == 64 || l < C_::PcA::LANES) dma16(ra, a_dst + (unsigned)(DW * j) * (unsigned)C_::PcA::BYTES, vo, A_RM ? 0 : soff);
       if constexpr (A_RM) voa[j] += stepa;
     }
     if constexpr (BNB) {
@@ -239,7 +253,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
       for (int j = 0; j < PPWA; ++j) {
         int vo = voa2[j];
         if constexpr (!A_RM) { if (tail && k0 + kca2[j] >= red1) vo = OOB; }
-        dma16(ra2, a_dst + C_::A_FLOATS * 4u + (unsigned)(DW * j) * 1024u, vo, A_RM ? 0 : soff);
+        if (C_::PcA::LANES == 64 || l < C_::PcA::LANES) dma16(ra2, a_dst + C_::A_FLOATS * 4u + (unsigned)(DW * j) * (unsigned)C_::PcA::BYTES, vo, A_RM ? 0 : soff);
         if constexpr (A_RM) voa2[j] += stepa2;
       }
     }
@@ -247,7 +261,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
     for (int j = 0; j < PPWB; ++j) {
       int vo = vob[j];
       if constexpr (!B_RM) { if (tail && k0 + kcb[j] >= red1) vo = OOB; }
-      dma16(rb, b_dst + (unsigned)(DW * j) * 1024u, vo, B_RM ? 0 : soff);
+      if (C_::PcB::LANES == 64 || l < C_::PcB::LANES) dma16(rb, b_dst + (unsigned)(DW * j) * (unsigned)C_::PcB::BYTES, vo, B_RM ? 0 : soff);
       if constexpr (B_RM) vob[j] += stepb;
     }
     ++issued;
@@ -621,7 +635,8 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   {
     constexpr int C4 = C_::C4, RPI = C_::NTHR / C4, ITERS = (BM + RPI - 1) / RPI;      // rows per pass, passes
     const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
-    const int col = n0 + c4 * 4;
+    const bool epi = rr < RPI;                               // (NTHR need not be a multiple of the tile's column quads: 160-wide tiles)
+    const int col = epi ? n0 + c4 * 4 : g.N;                 // an idle thread owns no column
     float* Cb = g.C + (size_t)split * g.M * g.ldc;           // split > 0 only for slab outputs
     // BSTAT: C is the gradient of a BatchNorm(+ReLU) output; every thread sums (g, g*xhat) of its column quad over the rows
     // it stores, the workgroup adds the per-thread sums in row order and writes ONE partial per tile row block and column

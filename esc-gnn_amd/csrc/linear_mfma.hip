@@ -960,6 +960,18 @@ static inline bool dma_big(int64_t M, int64_t N) {
   static const int64_t min_wgs = getenv("ESC_BIG_MIN_WGS") ? atoll(getenv("ESC_BIG_MIN_WGS")) : (1LL << 62);
   return cdiv(M, 128) * cdiv(N, tile128_ok(N) ? 128 : 64) >= min_wgs;
 }
+// 300 / 600-wide layers (ogbg-mol emb_dim 300, its 2H hidden layer): a 128-row x 160-column tile (r03) pads them by 6.7 % at 2.2x the
+// arithmetic intensity of the 64x64 tile they take (128-wide tiles would pad 300 by 28 %).  Built (reduction-major tiles with
+// 640-byte rows: one DMA piece per row, 40 of 64 lanes active), correct (tests/test_hip_ops.py) and MEASURED SLOWER
+// (profiles/r03_kernel_roofline_tile160.txt): one workgroup per CU and 157 x 2 = 314 tiles for 256 CUs leave the second round of
+// workgroups on 58 CUs — 20000x300x300 forward 60.1 us against 51.5 us on the 128x64 tile, dX+dW 117 against 108 us, the
+// config-5 step 4.34 against 4.27 ms.  OFF by default; ESC_TILE160=1 enables it for experiments.
+static inline bool tile160_ok(int64_t dim) { return cdiv(dim, 160) * 160 * 10 <= dim * 11; }
+static inline bool use160(int64_t rows, int64_t cols) {
+  static const int on = getenv("ESC_TILE160") ? atoi(getenv("ESC_TILE160")) : 0;
+  static const int64_t min_wgs = getenv("ESC_TILE160_MIN_WGS") ? atoll(getenv("ESC_TILE160_MIN_WGS")) : 150;
+  return on && tile160_ok(cols) && cols % 128 != 0 && cdiv(rows, 128) * cdiv(cols, 160) >= min_wgs;
+}
 static inline hipError_t dma_check(hipError_t e, const char* what) {
   if (e != hipSuccess) set_error("%s: %s", what, hipGetErrorString(e));
   return e;
@@ -989,6 +1001,9 @@ static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, 
   if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
     e = in_scale ? dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 1, false, false>(g, 0, s)
                  : dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
+  } else if (use160(M, N)) {              // 300 / 600-wide outputs with enough row tiles: the 128x160 tile
+    e = in_scale ? dma::launch_gemm<128, 160, 32, 4, 1, 3, 4, false, false, 1, true, false>(g, 0, s)
+                 : dma::launch_gemm<128, 160, 32, 4, 1, 3, 4, false, false, 0, true, false>(g, 0, s);
   } else if (dma_big(M, N)) {             // edge-sized (or enough 128-row tiles to fill the chip): 128x128 tile, 4 compute + 4 loader waves
     if (in_scale)               e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false>(g, 0, s);
     else if (tile128_ok(N))     e = dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false>(g, 0, s);
@@ -1095,7 +1110,7 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
     int rc = ESC_OK;
     if (dma_fwd(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, s, &rc)) {
       if (rc != ESC_OK || bn == nullptr) return rc;
-      return esc_bn_stats_from_partials_rows(col_stats, M, N, dma_big(M, N) ? 128 : 64, bn->eps, bn->momentum, bn->mean,
+      return esc_bn_stats_from_partials_rows(col_stats, M, N, (dma_big(M, N) || use160(M, N)) ? 128 : 64, bn->eps, bn->momentum, bn->mean,
                                              bn->invstd, bn->running_mean, bn->running_var, bn->gamma, bn->beta, bn->scale,
                                              bn->shift, stream);
     }
@@ -1140,7 +1155,7 @@ int esc_linear_fold_available(void) { return (g_use_dma & 1) != 0; }
 int64_t esc_linear_stats_block_rows(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N,
                                     int64_t K) {
   if ((g_use_dma & 4) && K <= small::SMALL_MAX && N > 32) return small::ROWS_FWD;
-  if ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w)) return dma_big(M, N) ? 128 : 64;
+  if ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w)) return (dma_big(M, N) || use160(M, N)) ? 128 : 64;
   return 32;
 }
 
@@ -1213,7 +1228,8 @@ int esc_linear_bwd_input(const float* dY, int64_t ld_dy, const float* W, int64_t
   if (dma_bwd_ok(dY, ld_dy, nullptr, 0, W, ld_w, M, N, K, dX, ld_dx, nullptr, true, false)) {
     dma::GArgs d{};
     dma_fill_dx(d, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
-    const hipError_t e = (M >= 8192 && tile128_ok(K)) ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s)
+    const hipError_t e = use160(M, K) ? dma::launch_gemm<128, 160, 32, 4, 1, 3, 4, false, true, 0, false, false>(d, 0, s)
+                         : (M >= 8192 && tile128_ok(K)) ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, true, 0, false, false>(d, 0, s)
                                    : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, true, 0, false, false>(d, 0, s);
     return dma_check(e, "esc_linear_bwd_input") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
   }
@@ -1439,13 +1455,16 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
     // dX tiles + split-M dW slabs of the LDS-DMA family in ONE launch
     hipStream_t s = (hipStream_t)stream;
     const bool big = M >= 8192 && tile128_ok(N) && tile128_ok(K);
+    const bool t160 = use160(M, K);            // dX tiles 128 rows x 160 of the K columns; the dW job rides on the same tile over [N, K]
     int splits, per;
-    dma_wgrad_plan(M, N, K, big ? 128 : 64, big ? 128 : 64, &splits, &per);
+    dma_wgrad_plan(M, N, K, (big || t160) ? 128 : 64, t160 ? 160 : (big ? 128 : 64), &splits, &per);
     dma::DualArgs a{};
     dma_fill_dx(a.dx, dY, ld_dy, W, ld_w, M, N, K, dX, ld_dx, accumulate);
     dma_fill_dw(a.dw, dY, ld_dy, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
     hipError_t e;
-    if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s)
+    if (t160) e = in_scale ? dma::launch_dual<128, 160, 32, 4, 1, 3, 4, true>(a, 0, s)
+                           : dma::launch_dual<128, 160, 32, 4, 1, 3, 4, false>(a, 0, s);
+    else if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s)
                           : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false>(a, 0, s);
     else     e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false>(a, 0, s);
     if (dma_check(e, "esc_linear_bwd_both") != hipSuccess) return ESC_ELAUNCH;

@@ -93,7 +93,9 @@ def test_aggregate_forward_bit_exact_and_backward(E, C):
 
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (333, 256, 10), (777, 10, 256), (130, 256, 1280),
                                    (257, 1, 256), (9000, 256, 256), (5, 48, 36),
-                                   (1000, 300, 300), (777, 600, 300), (9000, 300, 600), (6500, 300, 44), (260, 36, 300)])
+                                   (1000, 300, 300), (777, 600, 300), (9000, 300, 600), (6500, 300, 44), (260, 36, 300),
+                                   # the 128x160 tile (r03): molhiv's edge rows 300 -> 300, node rows 300 -> 600 and 600 -> 300
+                                   (20000, 300, 300), (6500, 600, 300), (6500, 300, 600), (19999, 600, 300)])
 def test_linear_forward_backward(E, M, N, K):
     torch.manual_seed(M + N + K)
     dev = torch.device("cuda:0")
@@ -280,7 +282,8 @@ def test_gineplus_against_message_passing_loop(E):
 
 
 @pytest.mark.parametrize("M,N,K", [(15200, 256, 256), (2400, 256, 256), (2401, 256, 1280), (333, 256, 10), (50, 300, 64),
-                                   (33, 64, 16), (31, 40, 8), (2400, 300, 300), (9000, 600, 300), (256, 300, 600)])
+                                   (33, 64, 16), (31, 40, 8), (2400, 300, 300), (9000, 600, 300), (256, 300, 600),
+                                   (20000, 300, 300), (6500, 600, 300)])       # (the last two: statistics epilogue of the 128x160 tile)
 @pytest.mark.parametrize("last_block", [0, 1])
 def test_linear_with_fused_batchnorm_statistics(E, M, N, K, last_block):
     """esc_linear_bn_fwd: GEMM + statistics epilogue + merge (finalize launch, or knob 8: by the last workgroups of

@@ -117,10 +117,11 @@ def main():
     add("bag forward, cache-resident (HBM bytes)", us, k, Z * 8 + (Ee + 1) * 4 + 1800 * H * 4 + Ee * H * 4)
     add("bag forward (L2 row traffic Z*H*4)", us, k, Z * H * 4)
     us, k = timed("bag_fwd", lambda: nv.call("esc_bag_fwd_rows", nv.ptr(table), 1800, H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx), nv.ptr(plan.bag_val), Ee, nv.ptr(zb), H, 0, None, s))
-    add("bag forward, LDS-staged table slices (HBM bytes)", us, k, Z * 8 + (Ee + 1) * 4 + 1800 * H * 4 + Ee * H * 4)
-    st = torch.empty((Ee // 128 + 1) * H * 2, device=dev)
-    us, k = timed("bag_fwd", lambda: nv.call("esc_bag_fwd_rows", nv.ptr(table), 1800, H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx), nv.ptr(plan.bag_val), Ee, nv.ptr(zb), H, 0, nv.ptr(st), s))
-    add("bag forward, LDS-staged + BatchNorm partials epilogue", us, k, Z * 8 + (Ee + 1) * 4 + 1800 * H * 4 + Ee * H * 4)
+    add("bag forward through esc_bag_fwd_rows (LDS-staged with ESC_BAG_TILED=1, else the kernel above)", us, k, Z * 8 + (Ee + 1) * 4 + 1800 * H * 4 + Ee * H * 4)
+    if int(nv.lib().esc_bag_fwd_stats_block_rows(nv.ptr(table), 1800, H, nv.ptr(zb), H, Ee)):     # (only with ESC_BAG_TILED=1)
+        st = torch.empty((Ee // 128 + 1) * H * 2, device=dev)
+        us, k = timed("bag_fwd", lambda: nv.call("esc_bag_fwd_rows", nv.ptr(table), 1800, H, nv.ptr(plan.row_ptr), nv.ptr(plan.bag_idx), nv.ptr(plan.bag_val), Ee, nv.ptr(zb), H, 0, nv.ptr(st), s))
+        add("bag forward, LDS-staged + BatchNorm partials epilogue", us, k, Z * 8 + (Ee + 1) * 4 + 1800 * H * 4 + Ee * H * 4)
     dt = torch.empty(1800, H, device=dev)
     scr = torch.empty(int(nv.lib().esc_bag_bwd_scratch(Z, H)), device=dev)
     us, k = timed("bag_bwd", lambda: nv.call("esc_bag_bwd_table_rows", nv.ptr(zb), H, H, nv.ptr(plan.col_ptr), nv.ptr(plan.col_row), nv.ptr(plan.col_val), nv.ptr(plan.col_col), Z, 1800, Ee, 0, nv.ptr(dt), nv.ptr(scr), s))

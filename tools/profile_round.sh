@@ -15,7 +15,7 @@ STEPS="--steps 30 --warmup 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 bench.py $STEPS > "$OUT/bench_under_rocprof.log" 2>&1
 cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
 # the JSON line bench.py printed IN THE TRACED RUN: its roofline.avg_us (live event pairs) and the AverageNs of
-# agg_fwd_wave<4> in the stats above describe the same launches — the pair the judge can cross-check
+# agg_fwd_wave<2> in the stats above describe the same launches — the pair the judge can cross-check
 grep '^{"metric"' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json.log" || true
 python3 tools/step_timeline.py "$(find "$OUT/kt" -name '*kernel_trace.csv' | head -1)" 2 > "$OUT/${TAG}_step_timeline.txt" || true
 echo "[profile] kernel trace done"
@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write
 echo "[profile] WRITE_SIZE pass done"
 F=$(find "$OUT/pmc_fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/pmc_write" -name '*counter_collection.csv' | head -1)
-python3 tools/parse_pmc.py "$F" "$W" "agg_fwd_wave<4" "$OUT/${TAG}_traffic_agg_fwd.json"
+python3 tools/parse_pmc.py "$F" "$W" "agg_fwd_wave<2" "$OUT/${TAG}_traffic_agg_fwd.json"
 grep -E "agg_fwd_wave|bag_fwd|Kernel_Name" "$F" > "$OUT/${TAG}_pmc_fetch_agg_bag.csv" || true
 grep -E "agg_fwd_wave|bag_fwd|Kernel_Name" "$W" > "$OUT/${TAG}_pmc_write_agg_bag.csv" || true
 
@@ -37,11 +37,11 @@ cat "$OUT/${TAG}_bench.json.log"
 python3 - "$OUT/${TAG}_bench_kernel_stats.csv" "$OUT/${TAG}_bench_under_rocprof.json.log" "$OUT/${TAG}_bench.json.log" > "$OUT/${TAG}_roofline_check.txt" <<'PY' || true
 import csv, json, sys
 rows = {r["Name"]: r for r in csv.DictReader(open(sys.argv[1]))}
-agg = next((r for n, r in rows.items() if "agg_fwd_wave<4" in n), None)
+agg = next((r for n, r in rows.items() if "agg_fwd_wave<2" in n), None)
 line = json.loads(open(sys.argv[2]).read())
 plain = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
 rf = line["roofline"]; alg = rf["alg_bytes_per_launch"]
-print("kernel esc::agg_fwd_wave<4, true> (the wide scatter-add launches of the step), algorithmic bytes per launch %d:" % alg)
+print("kernel esc::agg_fwd_wave<2, true> (the wide scatter-add launches of the step, two waves per destination row), algorithmic bytes per launch %d:" % alg)
 t = float(agg["AverageNs"]) * 1e-3
 print("  traced run, rocprofv3 kernel stats        : %d calls, average %.2f us -> %.0f GB/s = %.3f of 8 TB/s" % (int(agg["Calls"]), t, alg / t / 1e3, alg / t / 1e3 / 8000))
 print("  traced run, bench.py event pairs          : %d launches, average %.2f us -> frac %.3f (under the tracer the start marker queues behind the profiler's packets)" % (rf["launches"], rf["avg_us"], rf["frac"]))
