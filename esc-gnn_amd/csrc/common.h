@@ -206,7 +206,7 @@ struct BnbDev {
   const float* x; int ldx;
   const float* mean; const float* invstd; const float* scale; const float* shift;
   const float2* coef;
-  int relu;
+  int relu;                         // activation behind the BatchNorm: 0 none, 1 ReLU, 2 ELU (the fused-activation codes of norm.hip)
 };
 // ... and the column sums (sum g, sum g*xhat) of the NEXT BatchNorm backward, taken over the rows of every output tile in
 // the epilogue (PRO bit 3): C is the gradient of that BatchNorm's output, `x` what it normalised; partial[tile_m][col].
@@ -222,6 +222,13 @@ struct BnStatDev {
 __device__ __forceinline__ float bnb_apply(float gv, float xv, float mu, float a, float ms, float mh, float k1, float k2) {
   const float gm = fmaf(xv, ms, mh) > 0.f ? gv : 0.f;
   return a * fmaf(mu - xv, k2, gm - k1);                               // = a * (g - k1 - (x - mu) * invstd * k2)
+}
+// ... with ELU(alpha = 1) behind the BatchNorm (zinc_models.py:513-522): d act / d v = v > 0 ? 1 : exp(v), v = the pre-activation
+// the forward formed (fmaf(x, scale, shift)); `elu` is wave-uniform
+__device__ __forceinline__ float bnb_apply_act(float gv, float xv, float mu, float a, float ms, float mh, float k1, float k2, bool elu) {
+  const float v = fmaf(xv, ms, mh);
+  const float gm = v > 0.f ? gv : (elu ? gv * expf(v) : 0.f);
+  return a * fmaf(mu - xv, k2, gm - k1);
 }
 
 }  // namespace esc

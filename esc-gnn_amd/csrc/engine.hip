@@ -162,6 +162,7 @@ static int linear_backward(const Ctx& c, const float* dY, int64_t ld_dy, const f
 // BatchNorm come out of the dX epilogue of its second Linear (bit 1): partial/finalize -> dX+dW -> finalize -> dX+dW.
 // ESC_BN_FUSE_BWD=0 restores the elementwise launches (A/B runs, bisecting).
 static int g_bn_fuse_bwd = getenv("ESC_BN_FUSE_BWD") ? atoi(getenv("ESC_BN_FUSE_BWD")) : 11;      // bit 2: the edge tail, see backward() (measured: no gain, off)
+static int g_bn_fuse_elu = getenv("ESC_BN_FUSE_ELU") ? atoi(getenv("ESC_BN_FUSE_ELU")) : 0;
 static esc_bn_bwd_fused bn_fused(const float* x, int64_t ld_x, const BnWs& w, int relu) {
   return esc_bn_bwd_fused{x, ld_x, w.mean, w.invstd, w.scale, w.shift, w.coef, relu};
 }
@@ -474,19 +475,31 @@ static int mlp_forward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const f
 }
 
 // given dOut (grad of the materialised output `out`), produce parameter grads and, if dA != NULL, dA
-// will mlp_backward take the fused form (see g_bn_fuse_bwd)?  ReLU MLPs whose hidden activation was never materialised,
-// statistics of this rank only, shapes the fused kernels serve
-static bool mlp_backward_fused(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M, const float* out,
-                               int64_t ld_out, const float* dOut, int64_t ld_dout, const float* dA, int64_t ld_da, bool pre_out) {
+// Which of an MLP's two Linear backwards take the fused form (see g_bn_fuse_bwd)?  ReLU MLPs whose hidden activation was never
+// materialised (counting model) and ELU MLPs with a materialised one (ZINC), statistics of this rank only, shapes the fused
+// kernels serve; lin0 only together with lin1.
+struct MlpFuse { bool lin1 = false, lin0 = false; };
+static MlpFuse mlp_fuse_plan(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M, const float* out,
+                             int64_t ld_out, const float* dOut, int64_t ld_dout, const float* dA, int64_t ld_da, bool pre_out) {
   const Layout& y = c.y;
   const int64_t H = y.H;
-  if (!((g_bn_fuse_bwd & 1) && c.train && c.act == 1 && w.A1 == nullptr && !sync_on(c) && y.bst_part != nullptr && p.lin1.in_dim == H && p.lin1.out_dim == H))
-    return false;
-  const esc_bn_bwd_fused f1 = bn_fused(pre_out ? out : w.Y1, pre_out ? ld_out : H, w.b1, 1), f0 = bn_fused(w.Y0, H, w.b0, 1);
-  const esc_bn_bwd_next n0{y.bst_part, w.Y0, H, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, 1};
+  MlpFuse f;
+  if (!((g_bn_fuse_bwd & 1) && c.train && !sync_on(c) && y.bst_part != nullptr && p.lin1.in_dim == H && p.lin1.out_dim == H)) return f;
+  // (ELU: built and tested, but the exp in the operand staging costs more than the two launches it saves — ZINC config 4: 1.14 ms
+  // fused against 1.10 ms per step; ESC_BN_FUSE_ELU=1 enables it)
+  if (!((c.act == 1 && w.A1 == nullptr) || (c.act == 2 && w.A1 != nullptr && !pre_out && g_bn_fuse_elu))) return f;
+  const esc_bn_bwd_fused f1 = bn_fused(pre_out ? out : w.Y1, pre_out ? ld_out : H, w.b1, c.act), f0 = bn_fused(w.Y0, H, w.b0, c.act);
+  const esc_bn_bwd_next n0{y.bst_part, w.Y0, H, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, c.act};
   const float* slab_probe = c.jobs ? *c.slab_cursor : y.slabs;
-  return esc_linear_bwd_both_bn_ok(dOut, ld_dout, &f1, w.Y0, H, p.lin1.w, H, M, H, H, y.dT2, H, slab_probe, (g_bn_fuse_bwd & 2) ? &n0 : nullptr) != 0 &&
-         esc_linear_bwd_both_bn_ok(y.dT2, H, &f0, A, ld_a, p.lin0.w, p.lin0.in_dim, M, H, p.lin0.in_dim, dA, ld_da, slab_probe, nullptr) != 0;
+  const float* xh = w.A1 ? w.A1 : w.Y0;                    // lin1's input: the materialised activation, or its pre-BatchNorm rows
+  f.lin1 = esc_linear_bwd_both_bn_ok(dOut, ld_dout, &f1, xh, H, p.lin1.w, H, M, H, H, y.dT2, H, slab_probe, (g_bn_fuse_bwd & 2) ? &n0 : nullptr) != 0;
+  f.lin0 = f.lin1 && esc_linear_bwd_both_bn_ok(y.dT2, H, &f0, A, ld_a, p.lin0.w, p.lin0.in_dim, M, H, p.lin0.in_dim, dA, ld_da, slab_probe, nullptr) != 0;
+  return f;
+}
+// (callers that can leave BatchNorm 1's column sums ask whether they will be consumed)
+static bool mlp_backward_fused(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const float* A, int64_t ld_a, int64_t M, const float* out,
+                               int64_t ld_out, const float* dOut, int64_t ld_dout, const float* dA, int64_t ld_da, bool pre_out) {
+  return mlp_fuse_plan(c, p, w, A, ld_a, M, out, ld_out, dOut, ld_dout, dA, ld_da, pre_out).lin1;
 }
 // have_slots > 0: the column sums of BatchNorm 1's backward are already in c.y.bst_part (float2[have_slots][H], left by the
 // producer of dOut: the readout's dX epilogue or the next layer's aggregate backward)
@@ -495,26 +508,31 @@ static int mlp_backward(const Ctx& c, const esc_mlp_t& p, const MlpWs& w, const 
                         int64_t ld_da, bool pre_out = false, int64_t have_slots = 0) {
   const Layout& y = c.y;
   const int64_t H = y.H;
-  if (mlp_backward_fused(c, p, w, A, ld_a, M, out, ld_out, dOut, ld_dout, dA, ld_da, pre_out)) {
-    {
-      const float* x1 = pre_out ? out : w.Y1;                  // what BatchNorm 1 normalised
-      const int64_t ld_x1 = pre_out ? ld_out : H;
-      const esc_bn_bwd_fused f1 = bn_fused(x1, ld_x1, w.b1, 1), f0 = bn_fused(w.Y0, H, w.b0, 1);
-      esc_bn_bwd_next n0{y.bst_part, w.Y0, H, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, 1};
-      const bool stats = (g_bn_fuse_bwd & 2) != 0;
-      if (have_slots > 0)
-        ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, have_slots, M, H, w.b1.coef, p.bn1.dgamma, p.bn1.dbeta, c.s));
-      else
-        ESC_TRY(esc_bn_bwd_coef(x1, ld_x1, nullptr, 0, dOut, ld_dout, M, H, w.b1.mean, w.b1.invstd, p.bn1.gamma, p.bn1.beta, 1, w.b1.coef,
-                                p.bn1.dgamma, p.bn1.dbeta, y.bn_scratch, c.s));
-      ESC_TRY(linear_backward_bn(c, dOut, ld_dout, f1, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1, M, y.dT2, H, 0, stats ? &n0 : nullptr));
-      if (stats)
-        ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, cdiv(M, esc_linear_bwd_bn_block_rows(M, H, H)), M, H, w.b0.coef, p.bn0.dgamma, p.bn0.dbeta, c.s));
-      else
-        ESC_TRY(esc_bn_bwd_coef(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, 1, w.b0.coef,
-                                p.bn0.dgamma, p.bn0.dbeta, y.bn_scratch, c.s));
-      return linear_backward_bn(c, y.dT2, H, f0, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0, nullptr);
-    }
+  const MlpFuse fuse = mlp_fuse_plan(c, p, w, A, ld_a, M, out, ld_out, dOut, ld_dout, dA, ld_da, pre_out);
+  if (fuse.lin1) {
+    const float* x1 = pre_out ? out : w.Y1;                  // what BatchNorm 1 normalised
+    const int64_t ld_x1 = pre_out ? ld_out : H;
+    const esc_bn_bwd_fused f1 = bn_fused(x1, ld_x1, w.b1, c.act), f0 = bn_fused(w.Y0, H, w.b0, c.act);
+    esc_bn_bwd_next n0{y.bst_part, w.Y0, H, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, c.act};
+    const bool stats = (g_bn_fuse_bwd & 2) != 0;
+    // (activation derivatives are recomputed from the pre-BatchNorm rows everywhere — Y == NULL — so that the sums and the
+    // fused apply see the same values)
+    if (have_slots > 0)
+      ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, have_slots, M, H, w.b1.coef, p.bn1.dgamma, p.bn1.dbeta, c.s));
+    else
+      ESC_TRY(esc_bn_bwd_coef(x1, ld_x1, nullptr, 0, dOut, ld_dout, M, H, w.b1.mean, w.b1.invstd, p.bn1.gamma, p.bn1.beta, c.act, w.b1.coef,
+                              p.bn1.dgamma, p.bn1.dbeta, y.bn_scratch, c.s));
+    if (w.A1) ESC_TRY(linear_backward_bn(c, dOut, ld_dout, f1, w.A1, H, nullptr, nullptr, p.lin1, M, y.dT2, H, 0, stats ? &n0 : nullptr));
+    else      ESC_TRY(linear_backward_bn(c, dOut, ld_dout, f1, w.Y0, H, w.b0.scale, w.b0.shift, p.lin1, M, y.dT2, H, 0, stats ? &n0 : nullptr));
+    if (stats)
+      ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, cdiv(M, esc_linear_bwd_bn_block_rows(M, H, H)), M, H, w.b0.coef, p.bn0.dgamma, p.bn0.dbeta, c.s));
+    else
+      ESC_TRY(esc_bn_bwd_coef(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, c.act, w.b0.coef,
+                              p.bn0.dgamma, p.bn0.dbeta, y.bn_scratch, c.s));
+    if (fuse.lin0) return linear_backward_bn(c, y.dT2, H, f0, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0, nullptr);
+    // lin0's shape is not served by the fused kernels (e.g. a 32-wide input): the apply as its own pass, then the plain backward
+    ESC_TRY(esc_bn_bwd_apply(w.Y0, H, nullptr, 0, y.dT2, H, M, H, w.b0.mean, w.b0.invstd, p.bn0.gamma, p.bn0.beta, c.act, w.b0.coef, y.dT2, H, c.s));
+    return linear_backward(c, y.dT2, H, A, ld_a, nullptr, nullptr, p.lin0, M, dA, ld_da, 0);
   }
   if (pre_out) ESC_TRY(bn_backward(c, out, ld_out, nullptr, 0, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));   // `out` = pre-BN rows
   else         ESC_TRY(bn_backward(c, w.Y1, H, out, ld_out, dOut, ld_dout, M, w.b1, p.bn1, y.dT1, H, y.bn_scratch));
@@ -899,6 +917,7 @@ static Layout plan_layout_zinc(const esc_zinc_gin_t* m, int64_t N, int64_t E, in
   y.col_stats_e = a.take(2 * (E / 32 + 1) * H);
   if (train) {
     y.dcat = a.take(N * y.W); y.dpool = a.take(G * y.W); y.dAl = a.take(G * H);
+    y.bst_part = a.take(2 * (N / 4 + E / 64 + 4) * H);
     y.dT1 = a.take(N * H); y.dT2 = a.take(N * H); y.dagg = a.take(N * H); y.dX0 = a.take(N * C0);
     y.dZcat = a.take(E * y.Wz); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
     for (int l = 0; l < L; ++l) y.d_e[l] = a.take(E * (l == 0 ? C0 : H));
@@ -1014,9 +1033,29 @@ static int backward_zinc(const ZincCtx& z) {
   ESC_TRY(esc_embed_bwd(y.dX0, C0, b->node_type, N, m->node_emb.rows, C0, m->node_emb.dw, c.s));
   // edge pipeline tail: edge-type table, z_embedding, bag
   ESC_TRY(esc_embed_bwd(y.dZcat + H, Wz, b->edge_type, E, m->edge_emb.rows, D, m->edge_emb.dw, ce.s));
-  ESC_TRY(bn_backward(ce, y.Yz, H, y.Zcat, Wz, y.dZcat, Wz, E, y.zb1, m->zbn1, y.dZemb, H, ce.y.bn_scratch));
-  ESC_TRY(linear_backward(ce, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
-  ESC_TRY(bn_backward(ce, y.Zb, H, y.A0, H, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, ce.y.bn_scratch));
+  // z_embedding's two BatchNorms ride on its Linear's backward when the fused kernels serve the shape (molecule batches: a few
+  // thousand edge rows, the node-sized tile): coef, dX+dW (apply on the staged dY, the first BatchNorm's sums from the dX epilogue),
+  // finalize, apply — instead of 3 + 1 + 3 launches
+  bool z_fused = false;
+  if ((g_bn_fuse_bwd & 3) == 3 && g_bn_fuse_elu && !sync_on(c) && y.bst_part != nullptr) {
+    const esc_bn_bwd_fused f1 = bn_fused(y.Yz, H, y.zb1, c.act);
+    const esc_bn_bwd_next n0{y.bst_part, y.Zb, H, y.zb0.mean, y.zb0.invstd, y.zb0.scale, y.zb0.shift, c.act};
+    const float* slab_probe = ce.jobs ? *ce.slab_cursor : y.slabs;
+    if (esc_linear_bwd_both_bn_ok(y.dZcat, Wz, &f1, y.A0, H, m->zlin.w, H, E, H, H, y.dAz, H, slab_probe, &n0)) {
+      ESC_TRY(esc_bn_bwd_coef(y.Yz, H, nullptr, 0, y.dZcat, Wz, E, H, y.zb1.mean, y.zb1.invstd, m->zbn1.gamma, m->zbn1.beta, c.act, y.zb1.coef,
+                              m->zbn1.dgamma, m->zbn1.dbeta, ce.y.bn_scratch, ce.s));
+      ESC_TRY(linear_backward_bn(ce, y.dZcat, Wz, f1, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0, &n0));
+      ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, cdiv(E, esc_linear_bwd_bn_block_rows(E, H, H)), E, H, y.zb0.coef, m->zbn0.dgamma,
+                                            m->zbn0.dbeta, ce.s));
+      ESC_TRY(esc_bn_bwd_apply(y.Zb, H, nullptr, 0, y.dAz, H, E, H, y.zb0.mean, y.zb0.invstd, m->zbn0.gamma, m->zbn0.beta, c.act, y.zb0.coef, y.dAz, H, ce.s));
+      z_fused = true;
+    }
+  }
+  if (!z_fused) {
+    ESC_TRY(bn_backward(ce, y.Yz, H, y.Zcat, Wz, y.dZcat, Wz, E, y.zb1, m->zbn1, y.dZemb, H, ce.y.bn_scratch));
+    ESC_TRY(linear_backward(ce, y.dZemb, H, y.A0, H, nullptr, nullptr, m->zlin, E, y.dAz, H, 0));
+    ESC_TRY(bn_backward(ce, y.Zb, H, y.A0, H, y.dAz, H, E, y.zb0, m->zbn0, y.dAz, H, ce.y.bn_scratch));
+  }
   ESC_TRY(esc_bag_bwd_table_rows(y.dAz, H, H, b->col_ptr, b->col_row, b->col_val, b->col_col, y.Z, m->z_rows, E, 1,
                                  m->dz_table, y.bag_scratch, ce.s));
   if (es.ok && !edge_jobs.empty()) ESC_TRY(esc_slab_reduce_jobs(edge_jobs.data(), (int)edge_jobs.size(), es.stream));

@@ -306,6 +306,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   }
   // BNB on a KC A (input-gradient tiles): six per-k arrays over the whole reduction range; k >= R: scale 0 -> operand 0
   float* bnbc = lds + C_::RING_FLOATS + C_::PRO_FLOATS;
+  const bool bnb_elu = BNB && g.bnb.relu == 2;               // (wave-uniform) ELU behind the fused BatchNorm backward
   const int bnb_s = ((g.R + BK - 1) / BK) * BK;              // stride of the six coefficient arrays
   if constexpr (BNB && !A_RM) {
     const int S = bnb_s;
@@ -437,10 +438,10 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
         for (int i = 0; i < MT; ++i) {
           float4& v = af[q][i];
           const float4 x = xf[q][i];
-          v.x = bnb_apply(v.x, x.x, b6[q][0].x, b6[q][1].x, b6[q][2].x, b6[q][3].x, b6[q][4].x, b6[q][5].x);
-          v.y = bnb_apply(v.y, x.y, b6[q][0].y, b6[q][1].y, b6[q][2].y, b6[q][3].y, b6[q][4].y, b6[q][5].y);
-          v.z = bnb_apply(v.z, x.z, b6[q][0].z, b6[q][1].z, b6[q][2].z, b6[q][3].z, b6[q][4].z, b6[q][5].z);
-          v.w = bnb_apply(v.w, x.w, b6[q][0].w, b6[q][1].w, b6[q][2].w, b6[q][3].w, b6[q][4].w, b6[q][5].w);
+          v.x = bnb_apply_act(v.x, x.x, b6[q][0].x, b6[q][1].x, b6[q][2].x, b6[q][3].x, b6[q][4].x, b6[q][5].x, bnb_elu);
+          v.y = bnb_apply_act(v.y, x.y, b6[q][0].y, b6[q][1].y, b6[q][2].y, b6[q][3].y, b6[q][4].y, b6[q][5].y, bnb_elu);
+          v.z = bnb_apply_act(v.z, x.z, b6[q][0].z, b6[q][1].z, b6[q][2].z, b6[q][3].z, b6[q][4].z, b6[q][5].z, bnb_elu);
+          v.w = bnb_apply_act(v.w, x.w, b6[q][0].w, b6[q][1].w, b6[q][2].w, b6[q][3].w, b6[q][4].w, b6[q][5].w, bnb_elu);
         }
       }
       if constexpr (BNB && A_RM) {        // ... per-column coefficients; reduction rows past the split's end contribute nothing
@@ -449,10 +450,10 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
         for (int i = 0; i < MT; ++i) {
           float4& v = af[q][i];
           const float4 x = xf[q][i];
-          v.x = r0 + 0 < red1 ? bnb_apply(v.x, x.x, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
-          v.y = r0 + 1 < red1 ? bnb_apply(v.y, x.y, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
-          v.z = r0 + 2 < red1 ? bnb_apply(v.z, x.z, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
-          v.w = r0 + 3 < red1 ? bnb_apply(v.w, x.w, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;
+          v.x = r0 + 0 < red1 ? bnb_apply_act(v.x, x.x, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
+          v.y = r0 + 1 < red1 ? bnb_apply_act(v.y, x.y, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
+          v.z = r0 + 2 < red1 ? bnb_apply_act(v.z, x.z, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
+          v.w = r0 + 3 < red1 ? bnb_apply_act(v.w, x.w, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
           if constexpr (DB) dbfrag[i] += (v.x + v.y) + (v.z + v.w);      // bias gradient: this lane's share of its column's sum
         }
       }
@@ -675,8 +676,10 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
             if constexpr (BSTAT) {
               if (bstat) {
                 const float4 y = ypre[it];
-                const float gx = fmaf(y.x, e_ms.x, e_mh.x) > 0.f ? v.x : 0.f, gy = fmaf(y.y, e_ms.y, e_mh.y) > 0.f ? v.y : 0.f;
-                const float gz = fmaf(y.z, e_ms.z, e_mh.z) > 0.f ? v.z : 0.f, gw = fmaf(y.w, e_ms.w, e_mh.w) > 0.f ? v.w : 0.f;
+                const bool elu = g.bst.relu == 2;            // (workgroup-uniform)
+                const float px = fmaf(y.x, e_ms.x, e_mh.x), py = fmaf(y.y, e_ms.y, e_mh.y), pz = fmaf(y.z, e_ms.z, e_mh.z), pw = fmaf(y.w, e_ms.w, e_mh.w);
+                const float gx = px > 0.f ? v.x : (elu ? v.x * expf(px) : 0.f), gy = py > 0.f ? v.y : (elu ? v.y * expf(py) : 0.f);
+                const float gz = pz > 0.f ? v.z : (elu ? v.z * expf(pz) : 0.f), gw = pw > 0.f ? v.w : (elu ? v.w * expf(pw) : 0.f);
                 t1.x += gx; t1.y += gy; t1.z += gz; t1.w += gw;
                 t2.x = fmaf(gx, (y.x - e_mu.x) * e_is.x, t2.x); t2.y = fmaf(gy, (y.y - e_mu.y) * e_is.y, t2.y);
                 t2.z = fmaf(gz, (y.z - e_mu.z) * e_is.z, t2.z); t2.w = fmaf(gw, (y.w - e_mu.w) * e_is.w, t2.w);

@@ -1520,10 +1520,10 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
 
 // ---- Linear backward with the BatchNorm(+ReLU) backward of its dY folded in (include/escgnn_hip.h, r03) ----------------
 static inline BnbDev bnb_dev(const esc_bn_bwd_fused* b) {
-  return BnbDev{b->x, (int)b->ld_x, b->mean, b->invstd, b->scale, b->shift, reinterpret_cast<const float2*>(b->coef), b->relu ? 1 : 0};
+  return BnbDev{b->x, (int)b->ld_x, b->mean, b->invstd, b->scale, b->shift, reinterpret_cast<const float2*>(b->coef), b->relu};
 }
 static inline bool bnb_operands_ok(const esc_bn_bwd_fused* b, int64_t M, int64_t N) {
-  return b && b->x && b->mean && b->invstd && b->scale && b->shift && b->coef && (b->relu == 0 || b->relu == 1) && b->ld_x >= N &&
+  return b && b->x && b->mean && b->invstd && b->scale && b->shift && b->coef && b->relu >= 0 && b->relu <= 2 && b->ld_x >= N &&
          dma_ok(b->x, M, b->ld_x) && aligned16(b->mean) && aligned16(b->invstd) && aligned16(b->scale) && aligned16(b->shift) &&
          aligned16(b->coef);
 }
@@ -1546,7 +1546,7 @@ int esc_linear_bwd_both_bn_ok(const float* dOut, int64_t ld_dout, const esc_bn_b
   if (next) {
     if (!next->partial || !next->x || !next->mean || !next->invstd || !next->scale || !next->shift || next->ld_x < K || next->ld_x % 4 != 0 ||
         !aligned16(next->x) || !aligned16(next->mean) || !aligned16(next->invstd) || !aligned16(next->scale) || !aligned16(next->shift) ||
-        !aligned16(next->partial) || K % 4 != 0 || ld_dx % 4 != 0 || !aligned16(dX) || (next->relu != 0 && next->relu != 1))
+        !aligned16(next->partial) || K % 4 != 0 || ld_dx % 4 != 0 || !aligned16(dX) || next->relu < 0 || next->relu > 2)
       return 0;
   }
   return 1;
@@ -1595,7 +1595,7 @@ int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_
   dma_fill_dw(a.dw, dOut, ld_dout, X, ld_x, in_scale, in_shift, M, N, K, slabs, splits, per);
   a.dx.bnb = bd; a.dw.bnb = bd;
   if (next)
-    a.dx.bst = BnStatDev{reinterpret_cast<float2*>(next->partial), next->x, (int)next->ld_x, next->mean, next->invstd, next->scale, next->shift, next->relu ? 1 : 0};
+    a.dx.bst = BnStatDev{reinterpret_cast<float2*>(next->partial), next->x, (int)next->ld_x, next->mean, next->invstd, next->scale, next->shift, next->relu};
   hipError_t e;
   // (the third operand image of the fused apply costs a ring stage: two stages keep the workgroup at 54 KB, which fits beside
   // an edge-stream GEMM on a CU; three stages — 78 KB — measured slower inside the two-stream step)

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void wgrad_small(const float* __restrict__ dY,
 #pragma unroll 4
     for (int r = 0; r < rows; ++r) {
       float v = V[(size_t)(r0 + r) * ldv + t];
-      if constexpr (BNB) v = bnb_apply(v, bnb.x[(size_t)(r0 + r) * bnb.ldx + t], b_mu, b_a, b_ms, b_mh, b_k1, b_k2);
+      if constexpr (BNB) v = bnb_apply_act(v, bnb.x[(size_t)(r0 + r) * bnb.ldx + t], b_mu, b_a, b_ms, b_mh, b_k1, b_k2, bnb.relu == 2);
       if constexpr (PRO && !SMALL_K) v = fmaxf(fmaf(v, psc, psh), 0.f);
       if constexpr (SMALL_K) colsum += v;
 #pragma unroll
@@ -146,10 +146,11 @@ __global__ __launch_bounds__(256) void smalln_dx(const float* __restrict__ dY, i
       const float4 k01 = *reinterpret_cast<const float4*>(bnb.coef + c), k23 = *reinterpret_cast<const float4*>(bnb.coef + c + 2);
       float4 ms = make_float4(0.f, 0.f, 0.f, 0.f), mh = make_float4(1.f, 1.f, 1.f, 1.f);
       if (bnb.relu) { ms = a; mh = *reinterpret_cast<const float4*>(bnb.shift + c); }
-      v.x = bnb_apply(v.x, x.x, mu.x, a.x, ms.x, mh.x, k01.x, is.x * k01.y);
-      v.y = bnb_apply(v.y, x.y, mu.y, a.y, ms.y, mh.y, k01.z, is.y * k01.w);
-      v.z = bnb_apply(v.z, x.z, mu.z, a.z, ms.z, mh.z, k23.x, is.z * k23.y);
-      v.w = bnb_apply(v.w, x.w, mu.w, a.w, ms.w, mh.w, k23.z, is.w * k23.w);
+      const bool elu = bnb.relu == 2;
+      v.x = bnb_apply_act(v.x, x.x, mu.x, a.x, ms.x, mh.x, k01.x, is.x * k01.y, elu);
+      v.y = bnb_apply_act(v.y, x.y, mu.y, a.y, ms.y, mh.y, k01.z, is.y * k01.w, elu);
+      v.z = bnb_apply_act(v.z, x.z, mu.z, a.z, ms.z, mh.z, k23.x, is.z * k23.y, elu);
+      v.w = bnb_apply_act(v.w, x.w, mu.w, a.w, ms.w, mh.w, k23.z, is.w * k23.w, elu);
     }
     *reinterpret_cast<float4*>(ys + r * ldn + c) = v;
   }

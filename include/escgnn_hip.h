@@ -275,7 +275,8 @@ int esc_slab_reduce_jobs(const esc_reduce_job* jobs /* host array */, int count,
  *   dOut       gradient of the BatchNorm(+ReLU) OUTPUT [M, N]
  *   bn         its input rows, batch statistics, forward coefficients (scale = gamma*invstd, shift = beta - mean*scale, as
  *              esc_bn_stats writes them) and coef = float2[N] (sum g, sum g*xhat) / M from esc_bn_bwd_coef[_from_partials];
- *              relu in {0, 1} (the mask is recomputed as fmaf(x, scale, shift) > 0, the forward's own expression)
+ *              relu = the activation behind the BatchNorm: 0 none, 1 ReLU, 2 ELU (its derivative is recomputed from the
+ *              pre-activation fmaf(x, scale, shift), the forward's own expression: [v > 0], resp. v > 0 ? 1 : exp(v))
  *   next       optional: dX is itself the gradient of a BatchNorm(+ReLU) output over K channels whose input rows are
  *              next->x; the dX tiles then also write partial[row_block][K] = (sum g, sum g*xhat) of their rows
  *              (row blocks of esc_linear_bwd_bn_block_rows(M, N, K) rows) for esc_bn_bwd_coef_from_partials.

@@ -715,6 +715,8 @@ def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(
     (77, 64, 96, 0, False, 0, True),         # ragged rows, no activation
     (1500, 300, 600, 1, True, 0, True),      # widths that are not multiples of the 32-wide K-step
     (333, 128, 16, 1, True, 0, False),
+    (2400, 256, 256, 2, False, 0, True),     # ELU behind both BatchNorms (zinc_models.py:513-522), materialised hidden activation
+    (3100, 256, 44, 2, False, 0, False),
     (15200, 256, 256, 1, False, 0, True),    # z_embedding.3 backward (edge rows: the 128x128 tile), both BatchNorms of the tail
     (9000, 256, 256, 1, True, 1, False),
 ])
@@ -769,7 +771,7 @@ def test_linear_backward_with_batchnorm_backward_folded_in(E, M, N, K, relu, pro
         slots = -(-M // rows)
         partial = torch.full((slots, K, 2), float("nan"), device=dev)
         nx = nv.BnBwdNext()
-        nx.partial, nx.x, nx.ld_x, nx.mean, nx.invstd, nx.scale, nx.shift, nx.relu = partial.data_ptr(), x2.data_ptr(), K, mean2.data_ptr(), invstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), 1
+        nx.partial, nx.x, nx.ld_x, nx.mean, nx.invstd, nx.scale, nx.shift, nx.relu = partial.data_ptr(), x2.data_ptr(), K, mean2.data_ptr(), invstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), (relu or 1)
     slabs = torch.empty(slab_n, device=dev)
     dX, dW, db = dx0.clone(), torch.full((N, K), float("nan"), device=dev), torch.full((N,), float("nan"), device=dev)
     assert nv.lib().esc_linear_bwd_both_bn_ok(nv.ptr(dOut), N, ctypes.byref(f), nv.ptr(X), ldx, nv.ptr(W), K, M, N, K, nv.ptr(dX), K, nv.ptr(slabs),
@@ -789,7 +791,7 @@ def test_linear_backward_with_batchnorm_backward_folded_in(E, M, N, K, relu, pro
     W64 = W.double().cpu().requires_grad_(True)
     # (Linear in front of the BatchNorm is irrelevant here: treat the BatchNorm input as a leaf and chain by hand)
     y = torch.nn.functional.batch_norm(xb64, None, None, ga64, be64, True, 0.1, 1e-5)
-    y = y.relu() if relu else y
+    y = y.relu() if relu == 1 else (torch.nn.functional.elu(y) if relu == 2 else y)
     y.backward(dOut.double().cpu())
     dY64 = xb64.grad
     _chk(dY, dY64, "unfused dY")
@@ -804,7 +806,7 @@ def test_linear_backward_with_batchnorm_backward_folded_in(E, M, N, K, relu, pro
         nv.call("esc_bn_bwd_coef_from_partials", nv.ptr(partial), slots, M, K, nv.ptr(c2), nv.ptr(dg2), nv.ptr(db2), nv.stream())
         r2, rg2, rb2 = torch.empty(K, 2, device=dev), torch.empty(K, device=dev), torch.empty(K, device=dev)
         nv.call("esc_bn_bwd_coef", nv.ptr(x2), K, None, 0, nv.ptr(dX), K, M, K, nv.ptr(mean2), nv.ptr(invstd2), nv.ptr(g2), nv.ptr(b2),
-                1, nv.ptr(r2), nv.ptr(rg2), nv.ptr(rb2), nv.ptr(scratch), nv.stream())
+                (relu or 1), nv.ptr(r2), nv.ptr(rg2), nv.ptr(rb2), nv.ptr(scratch), nv.stream())
         assert not bool(torch.isnan(partial).any())
         for a, b, name in ((c2, r2, "coef"), (dg2, rg2, "dgamma"), (db2, rb2, "dbeta")):
             assert float((a - b).abs().max()) <= 1e-5 * scale_of(b) * max(1.0, M ** 0.5 / 10), (name, float((a - b).abs().max()))
