@@ -108,17 +108,22 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
 
 // ---- forward, LDS-staged table slices (r03) ------------------------------------------------------------------------------
 // The wave-per-row kernel above pulls Z rows of H floats through the L2 (563 MB for 21.9 MB of algorithmic bytes at config
-// 1: 23.7 us at ~24 TB/s of L2 traffic).  A block of consecutive edges touches few DISTINCT table rows (the edges of one
-// or two graphs share their histogram bins: ~60-150 of the 1800 rows), so a workgroup owns BAG_EB edges x a 64-column slice,
-// finds the rows its edges use, stages those rows' slices in LDS ONCE (<= BAG_CAP rows x 256 B) and serves every entry from
-// there: the L2 only sees each used (row, slice) once per workgroup.  16 lanes x float4 cover the 64 columns of one edge,
-// so a wave walks 4 edges at a time; the entry lists travel 16 entries per load and are broadcast inside the 16-lane
-// group.  Per column the sum still runs over the entries in order with separately rounded products: bit-identical to the
-// kernel above (and to the sequential scatter).  A workgroup whose edges use more rows than fit reads them from global
-// memory in the same layout.  STATS: the workgroup also leaves the (mean, M2) of its BAG_EB rows per column — the BatchNorm
-// partials esc_bn_stats_from_partials_rows(block_rows = BAG_EB) merges, i.e. the statistics pass over the output is gone.
+// 1: 22.7 us at ~24.8 TB/s of L2 traffic).  A block of consecutive edges touches few DISTINCT table rows (the edges of one
+// or two graphs share their histogram bins: ~60-150 of the 1800 rows), so a workgroup owns BAG_EB edges x a 64-column slice and
+//   A. reads its edges' entry lists ONCE (they are contiguous: one coalesced sweep), marks the table rows they use, numbers
+//      those rows (any injective numbering will do) and rewrites the entries in LDS as (slot, count) pairs;
+//   B. stages the used rows' slices in LDS (<= BAG_CAP rows x 256 B);
+//   C. serves every entry from LDS: 16 lanes x float4 cover the 64 columns of one edge, a wave walks 4 edges at a time,
+//      8 entries per batch (8 entry reads, then 8 row reads, then the adds in entry order).
+// The L2 sees each used (row, slice) once per workgroup.  Per column the sum still runs over the entries in order with
+// separately rounded products: bit-identical to the kernel above (and to the sequential scatter).  A workgroup whose edges
+// use more rows / carry more entries than fit (or a count >= 65536) reads rows and entries from global memory in the same lane
+// layout.  STATS: the workgroup also leaves the (mean, M2) of its BAG_EB rows per column — the BatchNorm partials
+// esc_bn_stats_from_partials_rows(block_rows = BAG_EB) merges, i.e. the statistics pass over the output is gone.
+// (v1 of this kernel kept the entry lists in global memory and broadcast them with ds_bpermute: 70.9 us.)
 constexpr int BAG_EB = 128;          // edges per workgroup (32 per wave, 4 at a time)
-constexpr int BAG_CAP = 208;         // table rows a workgroup can stage: 208 x 256 B = 52 KB (two workgroups per CU)
+constexpr int BAG_CAP = 192;         // table rows a workgroup can stage: 192 x 256 B = 48 KB
+constexpr int BAG_ENT = 6144;        // entries a workgroup can keep in LDS (4 bytes each: slot | count << 16)
 constexpr int BAG_MAXROWS = 4096;    // table height the row map serves
 
 template <bool ACC, bool STATS>
@@ -127,33 +132,45 @@ __global__ __launch_bounds__(256) void bag_fwd_tiled(const float* __restrict__ t
                                                      const int* __restrict__ val, int E, float* __restrict__ out, int64_t ld_out,
                                                      float2* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* tile = reinterpret_cast<float*>(smem);                                     // [BAG_CAP][64]
-  unsigned short* map = reinterpret_cast<unsigned short*>(smem + BAG_CAP * 256);      // [rows] -> slot, 0xFFFF = unused
-  unsigned short* list = map + ((rows + 7) & ~7);                                     // [BAG_CAP] slot -> row
-  __shared__ int n_active;
+  float* tile = reinterpret_cast<float*>(smem);                                           // [BAG_CAP][64]
+  unsigned* ent = reinterpret_cast<unsigned*>(smem + BAG_CAP * 256);                      // [BAG_ENT]
+  unsigned short* map = reinterpret_cast<unsigned short*>(smem + BAG_CAP * 256 + BAG_ENT * 4);   // [rows] -> slot, 0xFFFF = unused
+  unsigned short* list = map + ((rows + 7) & ~7);                                         // [BAG_CAP] slot -> row
+  __shared__ int n_active, bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.x * 64;                                  // this workgroup's column slice
   const int e0 = blockIdx.y * BAG_EB, e1 = min(E, e0 + BAG_EB);
-  // 1. which table rows do these edges use?  (the entries of consecutive edges are consecutive)
+  const int zb = row_ptr[e0], ze = row_ptr[e1], nent = ze - zb;
+  // A. entries -> LDS, used rows marked
   for (int r = tid; r < rows; r += 256) map[r] = 0xFFFF;
-  if (tid == 0) n_active = 0;
+  if (tid == 0) { n_active = 0; bad = nent > BAG_ENT ? 1 : 0; }
   __syncthreads();
-  const int zb = row_ptr[e0], ze = row_ptr[e1];
-  for (int z = zb + tid; z < ze; z += 256) map[idx[z]] = 0xFFFE;   // (benign race: every writer stores the same mark)
+  if (nent <= BAG_ENT) {
+    for (int z = tid; z < nent; z += 256) {
+      const int r = idx[zb + z], v = val[zb + z];
+      if ((unsigned)v >= 65536u) bad = 1;                          // (benign race: every writer stores 1)
+      ent[z] = (unsigned)r | ((unsigned)v << 16);
+      map[r] = 0xFFFE;                                             // (benign race: the same mark)
+    }
+  }
   __syncthreads();
-  for (int r = tid; r < rows; r += 256) {
-    if (map[r] == 0xFFFE) {
-      const int sl = atomicAdd(&n_active, 1);                      // any injective numbering will do
-      map[r] = (unsigned short)min(sl, 0xFFF0);
-      if (sl < BAG_CAP) list[sl] = (unsigned short)r;
+  if (!bad) {
+    for (int r = tid; r < rows; r += 256) {
+      if (map[r] == 0xFFFE) {
+        const int sl = atomicAdd(&n_active, 1);
+        map[r] = (unsigned short)min(sl, 0xFFF0);
+        if (sl < BAG_CAP) list[sl] = (unsigned short)r;
+      }
     }
   }
   __syncthreads();
   const int na = n_active;
-  const bool staged = na <= BAG_CAP;                               // workgroup-uniform
+  const bool staged = !bad && na <= BAG_CAP;                       // workgroup-uniform
   const int g = lane >> 4, t = lane & 15;                          // 16-lane group = one edge, lane t owns columns c0 + 4t .. +3
   const bool col_ok = c0 + t * 4 < H;
-  if (staged) {      // 2. stage the used rows' slices: a 16-lane group copies one 256-byte piece
+  if (staged) {
+    for (int z = tid; z < nent; z += 256) { const unsigned e = ent[z]; ent[z] = (unsigned)map[e & 0xFFFFu] | (e & 0xFFFF0000u); }
+    // B. the used rows' slices: a 16-lane group copies one 256-byte piece
     for (int sl = wave * 4 + g; sl < na; sl += 16) {
       const int r = list[sl];
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -162,38 +179,53 @@ __global__ __launch_bounds__(256) void bag_fwd_tiled(const float* __restrict__ t
     }
   }
   __syncthreads();
-  // 3. the edges: wave w takes e0 + 32 w .. + 31, four at a time
+  // C. the edges: wave w takes e0 + 32 w .. + 31, four at a time; its 33 row pointers live in one register per lane
+  const int my_ptr = (lane <= 32 && e0 + wave * 32 + lane <= E) ? row_ptr[min(e0 + wave * 32 + lane, E)] : ze;
   float s_n = 0.f, s_mean[4] = {0.f, 0.f, 0.f, 0.f}, s_m2[4] = {0.f, 0.f, 0.f, 0.f};     // STATS: Welford over this lane's edges
   for (int it = 0; it < 8; ++it) {
     const int e = e0 + wave * 32 + it * 4 + g;
     const bool live = e < e1;
-    const int beg = live ? row_ptr[e] : 0, end = live ? row_ptr[e + 1] : 0;
+    const int pb = __shfl(my_ptr, it * 4 + g, 64), pe = __shfl(my_ptr, it * 4 + g + 1, 64);
+    const int beg = live ? pb : 0, len = live ? pe - pb : 0;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (ACC && live && col_ok) {
       const float4 q = *reinterpret_cast<const float4*>(out + (size_t)e * ld_out + c0 + t * 4);
       acc[0] = q.x; acc[1] = q.y; acc[2] = q.z; acc[3] = q.w;
     }
-    int longest = end - beg;                                       // the four edges of the wave run in lockstep
+    int longest = len;                                             // the four edges of the wave run in lockstep
     longest = max(longest, __shfl_xor(longest, 16, 64));
     longest = max(longest, __shfl_xor(longest, 32, 64));
-    for (int j = 0; j < longest; j += 16) {
-      // lane t of a group fetches entry j + t of its edge; slot (or row) and count are broadcast below
-      int my_r = 0; float my_v = 0.f;
-      if (beg + j + t < end) {
-        const int r = idx[beg + j + t];
-        my_r = staged ? (int)map[r] : r;
-        my_v = (float)val[beg + j + t];
+    if (staged) {
+      const unsigned* my = ent + (beg - zb);
+      for (int j = 0; j < longest; j += 8) {
+        unsigned ev[8];
+        float4 w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ev[k] = (j + k < len) ? my[j + k] : 0u;             // (one address per 16-lane group)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = *reinterpret_cast<const float4*>(tile + (ev[k] & 0xFFFFu) * 64 + t * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (j + k < len) {                                        // (a padded slot must not touch the sum: -0 + 0 = +0)
+            const float v = (float)(ev[k] >> 16);
+            acc[0] = __fadd_rn(acc[0], __fmul_rn(w[k].x, v)); acc[1] = __fadd_rn(acc[1], __fmul_rn(w[k].y, v));
+            acc[2] = __fadd_rn(acc[2], __fmul_rn(w[k].z, v)); acc[3] = __fadd_rn(acc[3], __fmul_rn(w[k].w, v));
+          }
+        }
       }
-      const int todo = min(16, longest - j);
-      for (int k = 0; k < todo; ++k) {
-        const int r = __shfl(my_r, (g << 4) + k, 64);
-        const float v = __shfl(my_v, (g << 4) + k, 64);
-        float4 w;
-        if (staged) w = *reinterpret_cast<const float4*>(tile + r * 64 + t * 4);
-        else        w = col_ok ? *reinterpret_cast<const float4*>(table + (size_t)r * H + c0 + t * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (beg + j + k < end) {                                    // (a padded slot must not touch the sum: -0 + 0 = +0)
-          acc[0] = __fadd_rn(acc[0], __fmul_rn(w.x, v)); acc[1] = __fadd_rn(acc[1], __fmul_rn(w.y, v));
-          acc[2] = __fadd_rn(acc[2], __fmul_rn(w.z, v)); acc[3] = __fadd_rn(acc[3], __fmul_rn(w.w, v));
+    } else {                                                        // rows and entries from global memory, same lane layout
+      for (int j = 0; j < longest; j += 16) {
+        int my_r = 0; float my_v = 0.f;
+        if (j + t < len) { my_r = idx[beg + j + t]; my_v = (float)val[beg + j + t]; }
+        const int todo = min(16, longest - j);
+        for (int k = 0; k < todo; ++k) {
+          const int r = __shfl(my_r, (g << 4) + k, 64);
+          const float v = __shfl(my_v, (g << 4) + k, 64);
+          const float4 w = col_ok ? *reinterpret_cast<const float4*>(table + (size_t)r * H + c0 + t * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j + k < len) {
+            acc[0] = __fadd_rn(acc[0], __fmul_rn(w.x, v)); acc[1] = __fadd_rn(acc[1], __fmul_rn(w.y, v));
+            acc[2] = __fadd_rn(acc[2], __fmul_rn(w.z, v)); acc[3] = __fadd_rn(acc[3], __fmul_rn(w.w, v));
+          }
         }
       }
     }
@@ -206,7 +238,7 @@ __global__ __launch_bounds__(256) void bag_fwd_tiled(const float* __restrict__ t
       }
     }
   }
-  if constexpr (STATS) {      // 4. (count, mean, M2) of the 16 lane groups x waves that share a column: Chan merge in a fixed order
+  if constexpr (STATS) {      // (count, mean, M2) of the 16 lane groups x waves that share a column: Chan merge in a fixed order
     __syncthreads();                                               // the tile is dead: reuse it, [16 contributors][64 columns][3]
     float* red = tile;
     const int contrib = wave * 4 + g;
@@ -474,7 +506,7 @@ static bool bag_tiled_ok(const float* table, int64_t rows, int64_t H, const floa
   return on && rows > 0 && rows <= esc::BAG_MAXROWS && H % 4 == 0 && ld_out % 4 == 0 && esc::aligned16(table) && esc::aligned16(out) &&
          E >= 4 * esc::BAG_EB && esc::cdiv(H, 64) <= 65535;
 }
-static size_t bag_tiled_lds(int64_t rows) { return (size_t)esc::BAG_CAP * 256 + (size_t)((rows + 7) & ~7) * 2 + (size_t)esc::BAG_CAP * 2 + 64; }
+static size_t bag_tiled_lds(int64_t rows) { return (size_t)esc::BAG_CAP * 256 + (size_t)esc::BAG_ENT * 4 + (size_t)((rows + 7) & ~7) * 2 + (size_t)esc::BAG_CAP * 2 + 64; }
 
 int esc_bag_fwd_rows(const float* table, int64_t rows, int64_t H, const int32_t* row_ptr, const int32_t* idx32, const int32_t* val32,
                      int64_t E, float* out, int64_t ld_out, int accumulate, float* stats, void* stream) {
@@ -490,6 +522,17 @@ int esc_bag_fwd_rows(const float* table, int64_t rows, int64_t H, const int32_t*
   const dim3 grid((unsigned)esc::cdiv(H, 64), (unsigned)esc::cdiv(E, esc::BAG_EB));
   const size_t lds = bag_tiled_lds(rows);
   float2* st = reinterpret_cast<float2*>(stats);
+  {      // more than the default 64 KB of dynamic LDS: raise the limit once per kernel
+    static bool raised = false;
+    if (!raised) {
+      const int want = (int)bag_tiled_lds(esc::BAG_MAXROWS);
+      bool ok = hipFuncSetAttribute((const void*)esc::bag_fwd_tiled<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)esc::bag_fwd_tiled<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)esc::bag_fwd_tiled<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+      if (!ok) { esc::set_error("esc_bag_fwd_rows: cannot raise the dynamic LDS limit"); return ESC_ELAUNCH; }
+      raised = true;
+    }
+  }
   if (accumulate)      esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_tiled<true, false>, grid, dim3(256), lds, s, table, (int)rows, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out, st);
   else if (stats)      esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_tiled<false, true>, grid, dim3(256), lds, s, table, (int)rows, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out, st);
   else                 esc::launch(ESC_K_BAG_FWD, esc::bag_fwd_tiled<false, false>, grid, dim3(256), lds, s, table, (int)rows, (int)H, row_ptr, idx32, val32, (int)E, out, ld_out, st);

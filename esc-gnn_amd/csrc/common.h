@@ -225,10 +225,15 @@ __device__ __forceinline__ float bnb_apply(float gv, float xv, float mu, float a
 }
 // ... with ELU(alpha = 1) behind the BatchNorm (zinc_models.py:513-522): d act / d v = v > 0 ? 1 : exp(v), v = the pre-activation
 // the forward formed (fmaf(x, scale, shift)); `elu` is wave-uniform
-__device__ __forceinline__ float bnb_apply_act(float gv, float xv, float mu, float a, float ms, float mh, float k1, float k2, bool elu) {
+__device__ __forceinline__ float bnb_apply_elu(float gv, float xv, float mu, float a, float ms, float mh, float k1, float k2) {
   const float v = fmaf(xv, ms, mh);
-  const float gm = v > 0.f ? gv : (elu ? gv * expf(v) : 0.f);
+  const float gm = v > 0.f ? gv : gv * expf(v);
   return a * fmaf(mu - xv, k2, gm - k1);
+}
+// (the flag is tested ONCE per call site on a wave-uniform value: callers branch around whole fragments, so that the ReLU path
+// carries no trace of the exp — folding the flag into the select cost the counting step 70 us)
+__device__ __forceinline__ float bnb_apply_act(float gv, float xv, float mu, float a, float ms, float mh, float k1, float k2, bool elu) {
+  return elu ? bnb_apply_elu(gv, xv, mu, a, ms, mh, k1, k2) : bnb_apply(gv, xv, mu, a, ms, mh, k1, k2);
 }
 
 }  // namespace esc

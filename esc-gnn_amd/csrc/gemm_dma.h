@@ -434,28 +434,32 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
         }
       }
       if constexpr (BNB && !A_RM) {       // BatchNorm backward on the staged gradient: per-k coefficients
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          float4& v = af[q][i];
-          const float4 x = xf[q][i];
-          v.x = bnb_apply_act(v.x, x.x, b6[q][0].x, b6[q][1].x, b6[q][2].x, b6[q][3].x, b6[q][4].x, b6[q][5].x, bnb_elu);
-          v.y = bnb_apply_act(v.y, x.y, b6[q][0].y, b6[q][1].y, b6[q][2].y, b6[q][3].y, b6[q][4].y, b6[q][5].y, bnb_elu);
-          v.z = bnb_apply_act(v.z, x.z, b6[q][0].z, b6[q][1].z, b6[q][2].z, b6[q][3].z, b6[q][4].z, b6[q][5].z, bnb_elu);
-          v.w = bnb_apply_act(v.w, x.w, b6[q][0].w, b6[q][1].w, b6[q][2].w, b6[q][3].w, b6[q][4].w, b6[q][5].w, bnb_elu);
+#define ESC_BNB_KC(FN)                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                       \
+          float4& v = af[q][i];                                                                                                \
+          const float4 x = xf[q][i];                                                                                           \
+          v.x = FN(v.x, x.x, b6[q][0].x, b6[q][1].x, b6[q][2].x, b6[q][3].x, b6[q][4].x, b6[q][5].x);                           \
+          v.y = FN(v.y, x.y, b6[q][0].y, b6[q][1].y, b6[q][2].y, b6[q][3].y, b6[q][4].y, b6[q][5].y);                           \
+          v.z = FN(v.z, x.z, b6[q][0].z, b6[q][1].z, b6[q][2].z, b6[q][3].z, b6[q][4].z, b6[q][5].z);                           \
+          v.w = FN(v.w, x.w, b6[q][0].w, b6[q][1].w, b6[q][2].w, b6[q][3].w, b6[q][4].w, b6[q][5].w);                           \
         }
+        if (bnb_elu) { ESC_BNB_KC(bnb_apply_elu) } else { ESC_BNB_KC(bnb_apply) }       // (wave-uniform: one scalar branch per fragment set)
+#undef ESC_BNB_KC
       }
       if constexpr (BNB && A_RM) {        // ... per-column coefficients; reduction rows past the split's end contribute nothing
         const int r0 = kstep0 + cq[q] * 8 + h * 4;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          float4& v = af[q][i];
-          const float4 x = xf[q][i];
-          v.x = r0 + 0 < red1 ? bnb_apply_act(v.x, x.x, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
-          v.y = r0 + 1 < red1 ? bnb_apply_act(v.y, x.y, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
-          v.z = r0 + 2 < red1 ? bnb_apply_act(v.z, x.z, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
-          v.w = r0 + 3 < red1 ? bnb_apply_act(v.w, x.w, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i], bnb_elu) : 0.f;
-          if constexpr (DB) dbfrag[i] += (v.x + v.y) + (v.z + v.w);      // bias gradient: this lane's share of its column's sum
+#define ESC_BNB_RM(FN)                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                       \
+          float4& v = af[q][i];                                                                                                \
+          const float4 x = xf[q][i];                                                                                           \
+          v.x = r0 + 0 < red1 ? FN(v.x, x.x, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;                         \
+          v.y = r0 + 1 < red1 ? FN(v.y, x.y, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;                         \
+          v.z = r0 + 2 < red1 ? FN(v.z, x.z, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;                         \
+          v.w = r0 + 3 < red1 ? FN(v.w, x.w, q_mu[i], q_a[i], q_ms[i], q_mh[i], q_k1[i], q_k2[i]) : 0.f;                         \
+          if constexpr (DB) dbfrag[i] += (v.x + v.y) + (v.z + v.w);                                                            \
         }
+        if (bnb_elu) { ESC_BNB_RM(bnb_apply_elu) } else { ESC_BNB_RM(bnb_apply) }
+#undef ESC_BNB_RM
       }
       if constexpr (P == 2) {
 #pragma unroll
@@ -676,10 +680,14 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
             if constexpr (BSTAT) {
               if (bstat) {
                 const float4 y = ypre[it];
-                const bool elu = g.bst.relu == 2;            // (workgroup-uniform)
                 const float px = fmaf(y.x, e_ms.x, e_mh.x), py = fmaf(y.y, e_ms.y, e_mh.y), pz = fmaf(y.z, e_ms.z, e_mh.z), pw = fmaf(y.w, e_ms.w, e_mh.w);
-                const float gx = px > 0.f ? v.x : (elu ? v.x * expf(px) : 0.f), gy = py > 0.f ? v.y : (elu ? v.y * expf(py) : 0.f);
-                const float gz = pz > 0.f ? v.z : (elu ? v.z * expf(pz) : 0.f), gw = pw > 0.f ? v.w : (elu ? v.w * expf(pw) : 0.f);
+                float gx, gy, gz, gw;
+                if (g.bst.relu == 2) {                       // (workgroup-uniform) ELU: d act / d v = v > 0 ? 1 : exp(v)
+                  gx = px > 0.f ? v.x : v.x * expf(px); gy = py > 0.f ? v.y : v.y * expf(py);
+                  gz = pz > 0.f ? v.z : v.z * expf(pz); gw = pw > 0.f ? v.w : v.w * expf(pw);
+                } else {
+                  gx = px > 0.f ? v.x : 0.f; gy = py > 0.f ? v.y : 0.f; gz = pz > 0.f ? v.z : 0.f; gw = pw > 0.f ? v.w : 0.f;
+                }
                 t1.x += gx; t1.y += gy; t1.z += gz; t1.w += gw;
                 t2.x = fmaf(gx, (y.x - e_mu.x) * e_is.x, t2.x); t2.y = fmaf(gy, (y.y - e_mu.y) * e_is.y, t2.y);
                 t2.z = fmaf(gz, (y.z - e_mu.z) * e_is.z, t2.z); t2.w = fmaf(gw, (y.w - e_mu.w) * e_is.w, t2.w);

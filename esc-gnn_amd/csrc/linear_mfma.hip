@@ -1570,14 +1570,18 @@ int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_
     const int splits = (int)cdiv(M, small::ROWS_WGRAD);
     float* db_part = slabs + (size_t)splits * N * K;
     const dim3 grid((unsigned)splits, (unsigned)cdiv(N, 256));
-    if (in_scale) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, true, true, true>, grid, dim3(256), 0, s, dOut, ld_dout, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, bd);
-    else          esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, true, false, true>, grid, dim3(256), 0, s, dOut, ld_dout, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, bd);
+#define ESC_WG(PR, ACT) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, true, PR, ACT>, grid, dim3(256), 0, s, dOut, ld_dout, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, bd)
+    if (bd.relu == 2) { if (in_scale) ESC_WG(true, 2); else ESC_WG(false, 2); }
+    else              { if (in_scale) ESC_WG(true, 1); else ESC_WG(false, 1); }
+#undef ESC_WG
     ESC_CHECK_LAUNCH("esc_linear_bwd_both_bn.small");
     if (dX != nullptr) {
       const size_t lds = (size_t)(32 + small::SMALL_MAX) * (N + 4) * sizeof(float);
       static size_t raised_to = 64 * 1024;
-      auto kern = small::smalln_dx<small::SMALL_MAX, true>;
-      if (dma_check(dma::raise_lds(kern, lds, raised_to), "esc_linear_bwd_both_bn") != hipSuccess) return ESC_ELAUNCH;
+      auto kern = bd.relu == 2 ? small::smalln_dx<small::SMALL_MAX, 2> : small::smalln_dx<small::SMALL_MAX, 1>;
+      if (dma_check(dma::raise_lds(small::smalln_dx<small::SMALL_MAX, 1>, lds, raised_to), "esc_linear_bwd_both_bn") != hipSuccess) return ESC_ELAUNCH;
+      static size_t raised_elu = 64 * 1024;
+      if (bd.relu == 2 && dma_check(dma::raise_lds(small::smalln_dx<small::SMALL_MAX, 2>, lds, raised_elu), "esc_linear_bwd_both_bn") != hipSuccess) return ESC_ELAUNCH;
       esc::launch(ESC_K_LINEAR, kern, dim3((unsigned)cdiv(M, 32)), dim3(256), lds, s, dOut, ld_dout, W, ld_w, (int)M, (int)N, (int)K, dX, ld_dx, accumulate, bd);
       ESC_CHECK_LAUNCH("esc_linear_bwd_both_bn.smalln");
     }

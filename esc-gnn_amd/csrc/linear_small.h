@@ -61,12 +61,12 @@ __global__ __launch_bounds__(256) void smallk_fwd(const float* __restrict__ X, i
 // !SMALL_K (small N): thread = k (a column of X), accumulators over n; dY rows are uniform.  act per thread column.
 // BNB (SMALL_K only): dY is the gradient of a BatchNorm(+ReLU) OUTPUT and its backward is applied as the column is read
 // (common.h BnbDev) — the elementwise launch in front of this one is gone.
-template <int SMAX, bool SMALL_K, bool PRO, bool BNB = false>
+template <int SMAX, bool SMALL_K, bool PRO, int BNB = 0>     // BNB: 0 plain dY, 1 fused BatchNorm backward (no activation / ReLU), 2 ... with ELU
 __global__ __launch_bounds__(256) void wgrad_small(const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X,
                                                    int64_t ldx, const float* __restrict__ sc, const float* __restrict__ sh,
                                                    int M, int N, int K, float* __restrict__ slabs, float* __restrict__ db_part,
                                                    BnbDev bnb) {
-  static_assert(!BNB || SMALL_K, "the fused BatchNorm backward transforms the wide dY operand");
+  static_assert(BNB == 0 || SMALL_K, "the fused BatchNorm backward transforms the wide dY operand");
   ESC_PRIO();
   __shared__ float us[ROWS_WGRAD * SMAX];            // the uniform operand's rows
   const int t = blockIdx.y * 256 + threadIdx.x;      // wide index: n (SMALL_K) or k
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void wgrad_small(const float* __restrict__ dY,
     float psc = 1.f, psh = 0.f;
     if constexpr (PRO && !SMALL_K) { psc = sc[t]; psh = sh[t]; }
     float b_mu = 0.f, b_a = 0.f, b_ms = 0.f, b_mh = 1.f, b_k1 = 0.f, b_k2 = 0.f;
-    if constexpr (BNB) {
+    if constexpr (BNB != 0) {
       const float2 kk = bnb.coef[t];
       b_mu = bnb.mean[t]; b_a = bnb.scale[t]; b_k1 = kk.x; b_k2 = bnb.invstd[t] * kk.y;
       if (bnb.relu) { b_ms = b_a; b_mh = bnb.shift[t]; }
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void wgrad_small(const float* __restrict__ dY,
 #pragma unroll 4
     for (int r = 0; r < rows; ++r) {
       float v = V[(size_t)(r0 + r) * ldv + t];
-      if constexpr (BNB) v = bnb_apply_act(v, bnb.x[(size_t)(r0 + r) * bnb.ldx + t], b_mu, b_a, b_ms, b_mh, b_k1, b_k2, bnb.relu == 2);
+      if constexpr (BNB == 1) v = bnb_apply(v, bnb.x[(size_t)(r0 + r) * bnb.ldx + t], b_mu, b_a, b_ms, b_mh, b_k1, b_k2);
+      if constexpr (BNB == 2) v = bnb_apply_elu(v, bnb.x[(size_t)(r0 + r) * bnb.ldx + t], b_mu, b_a, b_ms, b_mh, b_k1, b_k2);
       if constexpr (PRO && !SMALL_K) v = fmaxf(fmaf(v, psc, psh), 0.f);
       if constexpr (SMALL_K) colsum += v;
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void wgrad_small(const float* __restrict__ dY,
 }
 
 // dX[M,K<=16] = dY[M,N] W[N,K]: 32 rows per workgroup staged in LDS, thread (row, k-slot) walks the N-long dot product
-template <int KMAX, bool BNB = false>
+template <int KMAX, int BNB = 0>
 __global__ __launch_bounds__(256) void smalln_dx(const float* __restrict__ dY, int64_t lddy, const float* __restrict__ W,
                                                  int64_t ldw, int M, int N, int K, float* __restrict__ dX, int64_t lddx,
                                                  int accumulate, BnbDev bnb) {
@@ -139,18 +140,20 @@ __global__ __launch_bounds__(256) void smalln_dx(const float* __restrict__ dY, i
   for (int i = threadIdx.x; i < rows * (N / 4); i += 256) {
     const int r = i / (N / 4), c = (i % (N / 4)) * 4;
     float4 v = *reinterpret_cast<const float4*>(dY + (size_t)(r0 + r) * lddy + c);
-    if constexpr (BNB) {          // the BatchNorm backward of the staged gradient rows (per-channel coefficients: L1/L2 hits)
+    if constexpr (BNB != 0) {     // the BatchNorm backward of the staged gradient rows (per-channel coefficients: L1/L2 hits)
       const float4 x = *reinterpret_cast<const float4*>(bnb.x + (size_t)(r0 + r) * bnb.ldx + c);
       const float4 mu = *reinterpret_cast<const float4*>(bnb.mean + c), a = *reinterpret_cast<const float4*>(bnb.scale + c);
       const float4 is = *reinterpret_cast<const float4*>(bnb.invstd + c);
       const float4 k01 = *reinterpret_cast<const float4*>(bnb.coef + c), k23 = *reinterpret_cast<const float4*>(bnb.coef + c + 2);
       float4 ms = make_float4(0.f, 0.f, 0.f, 0.f), mh = make_float4(1.f, 1.f, 1.f, 1.f);
       if (bnb.relu) { ms = a; mh = *reinterpret_cast<const float4*>(bnb.shift + c); }
-      const bool elu = bnb.relu == 2;
-      v.x = bnb_apply_act(v.x, x.x, mu.x, a.x, ms.x, mh.x, k01.x, is.x * k01.y, elu);
-      v.y = bnb_apply_act(v.y, x.y, mu.y, a.y, ms.y, mh.y, k01.z, is.y * k01.w, elu);
-      v.z = bnb_apply_act(v.z, x.z, mu.z, a.z, ms.z, mh.z, k23.x, is.z * k23.y, elu);
-      v.w = bnb_apply_act(v.w, x.w, mu.w, a.w, ms.w, mh.w, k23.z, is.w * k23.w, elu);
+      if constexpr (BNB == 2) {
+        v.x = bnb_apply_elu(v.x, x.x, mu.x, a.x, ms.x, mh.x, k01.x, is.x * k01.y); v.y = bnb_apply_elu(v.y, x.y, mu.y, a.y, ms.y, mh.y, k01.z, is.y * k01.w);
+        v.z = bnb_apply_elu(v.z, x.z, mu.z, a.z, ms.z, mh.z, k23.x, is.z * k23.y); v.w = bnb_apply_elu(v.w, x.w, mu.w, a.w, ms.w, mh.w, k23.z, is.w * k23.w);
+      } else {
+        v.x = bnb_apply(v.x, x.x, mu.x, a.x, ms.x, mh.x, k01.x, is.x * k01.y); v.y = bnb_apply(v.y, x.y, mu.y, a.y, ms.y, mh.y, k01.z, is.y * k01.w);
+        v.z = bnb_apply(v.z, x.z, mu.z, a.z, ms.z, mh.z, k23.x, is.z * k23.y); v.w = bnb_apply(v.w, x.w, mu.w, a.w, ms.w, mh.w, k23.z, is.w * k23.w);
+      }
     }
     *reinterpret_cast<float4*>(ys + r * ldn + c) = v;
   }
