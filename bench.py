@@ -213,13 +213,15 @@ def main():
         other_mode = "strong" if args.scaling == "weak" else "weak"
         if other_mode == "strong" and rank != 0:           # strong: every rank slices the SAME split (rank 0's)
             g0 = build_count_dataset(0, args.graphs, h=args.h, use_rd=True, self_loop=True)
+            y0 = torch.cat([g.y.view(-1) for g in g0])          # the shared split's own normalisation: identical on every rank
             for g in g0:
-                g.y = (g.y.view(-1) - mean) / std
+                g.y = (g.y.view(-1) - y0.mean()) / y0.std()
             mode["store"] = DeviceGraphStore(g0, dev)
         elif other_mode == "weak" and rank != 0:           # weak: every rank walks its own split
             gr = build_count_dataset(rank * args.graphs, args.graphs, h=args.h, use_rd=True, self_loop=True)
+            yr = torch.cat([g.y.view(-1) for g in gr])
             for g in gr:
-                g.y = (g.y.view(-1) - mean) / std
+                g.y = (g.y.view(-1) - yr.mean()) / yr.std()
             mode["store"] = DeviceGraphStore(gr, dev)
         mode["scaling"] = other_mode
         nxt["b"] = None
