@@ -99,6 +99,7 @@ SIGNATURES = {
     "esc_slab_reduce_jobs": [P, I32, P],
     "esc_linear_bwd_both_bn_ok": [P, I64, POINTER(BnBwdFused), P, I64, P, I64, I64, I64, I64, P, I64, P, POINTER(BnBwdNext)],
     "esc_linear_bwd_bn_block_rows": [I64, I64, I64],
+    "esc_linear_bwd_set_wgrad_stream": [P],
     "esc_linear_bwd_both_bn": [P, I64, POINTER(BnBwdFused), P, I64, P, P, P, I64, I64, I64, I64, P, I64, I32, P, I64, P, P, P,
                                POINTER(BnBwdNext), P],
     "esc_bn_bwd_coef": [P, I64, P, I64, P, I64, I64, I64, P, P, P, P, I32, P, P, P, P, P],

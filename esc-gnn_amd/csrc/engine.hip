@@ -42,6 +42,7 @@ struct Layout {
   MlpWs xemb; float *cat, *Yl; BnWs bl; float *pred, *dpred;
   // backward scratch
   float *dcat, *dAl, *dT1, *dT2, *dagg, *dZemb, *dAz, *deps_part;
+  float *dT1_l[ESC_MAX_LAYERS], *dT2_l[ESC_MAX_LAYERS];   // per-layer copies: read by weight-gradient tiles that run behind the node chain (g_wgrad_stream)
   float* d_e[ESC_MAX_LAYERS];      // one per GINE layer: the edge stream consumes d_e[l] while the node chain moves on
   float *bn_scratch, *bag_scratch, *slabs;
   float *col_stats;               // GEMM-epilogue BatchNorm partials: float2[ceil(rows/32)][H]
@@ -94,6 +95,7 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
     y.dT1x = a.take(N * H); y.dT2x = a.take(N * H);
     y.slabs_x = a.take(esc_linear_bwd_weight_scratch(N, H, H));
     y.dcat = a.take(N * y.W); y.dAl = a.take(N * H); y.dT1 = a.take(N * H); y.dT2 = a.take(N * H);
+    for (int l = 0; l < L; ++l) { y.dT1_l[l] = a.take(N * H); y.dT2_l[l] = a.take(N * H); }
     y.dagg = a.take(N * H); y.dZemb = a.take(E * H); y.dAz = a.take(E * H);
     for (int l = 0; l < L; ++l) y.d_e[l] = a.take(E * (l == 0 ? C0 : H));
     y.deps_part = a.take(2 * N * (L > 0 ? L : 1));        // one vector per GINE layer, summed together at the end
@@ -130,6 +132,13 @@ struct Ctx {
   float** slab_cursor = nullptr;
   bool on_edge_stream = false;
   int act = 1;                                   // 1 ReLU (counting model), 2 ELU (ZINC): materialised activations
+  void* wgrad = nullptr;                         // != NULL: the node chain's weight-gradient tiles go to this stream (backward())
+};
+// While it lives, node-sized Linear backwards launched for `c` put their dW tiles on c.wgrad (esc_linear_bwd_set_wgrad_stream)
+struct WgradScope {
+  explicit WgradScope(const Ctx& c) : on_(c.wgrad != nullptr && !c.on_edge_stream && c.jobs != nullptr) { if (on_) (void)esc_linear_bwd_set_wgrad_stream(c.wgrad); }
+  ~WgradScope() { if (on_) (void)esc_linear_bwd_set_wgrad_stream(nullptr); }
+  bool on_;
 };
 
 // dX + dW tiles now, slab reduce deferred (or immediate when the context has no job list)
@@ -145,6 +154,7 @@ struct LdsFloorGuard {            // occupancy cap for the GEMMs launched while 
 static int linear_backward(const Ctx& c, const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* sc,
                            const float* sh, const esc_linear_t& lin, int64_t M, float* dX, int64_t ld_dx, int accumulate) {
   const LdsFloorGuard cap(c.on_edge_stream);
+  const WgradScope side(c);
   const int64_t N = lin.out_dim, K = lin.in_dim;
   if (c.jobs == nullptr)
     return esc_linear_bwd_both(dY, ld_dy, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db,
@@ -170,6 +180,7 @@ static int linear_backward_bn(const Ctx& c, const float* dOut, int64_t ld_dout, 
                               const float* sc, const float* sh, const esc_linear_t& lin, int64_t M, float* dX, int64_t ld_dx,
                               int accumulate, const esc_bn_bwd_next* next) {
   const LdsFloorGuard cap(c.on_edge_stream);
+  const WgradScope side(c);
   const int64_t N = lin.out_dim, K = lin.in_dim;
   if (c.jobs == nullptr)
     return esc_linear_bwd_both_bn(dOut, ld_dout, &f, X, ld_x, sc, sh, lin.w, K, M, N, K, dX, ld_dx, accumulate, lin.dw, K, lin.db, c.y.slabs,
@@ -268,10 +279,34 @@ static SideStream& side_stream() {
   }
   return ss;
 }
+// The node chain's backward waits for a Linear's dX only; its dW tiles (the larger half of the dual launch: 240 of 392 workgroups
+// at 2400 rows) are needed by the optimiser.  With this on they run on a third, lowest-priority stream behind the chain
+// (esc_linear_bwd_set_wgrad_stream), the scratch rows they read are per-layer copies, and the node-side slab reduce joins it.
+static int g_wgrad_stream = getenv("ESC_WGRAD_STREAM") ? atoi(getenv("ESC_WGRAD_STREAM")) : 0;
+struct WgradStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t joined = nullptr;
+  bool ok = false;
+};
+static WgradStream& wgrad_stream() {
+  static thread_local std::map<int, WgradStream> per_device;
+  static thread_local WgradStream off;   // ok == false
+  if (!g_wgrad_stream) return off;
+  WgradStream& ws = per_device[current_device()];
+  if (!ws.ok && ws.stream == nullptr) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    bool good = hipStreamCreateWithPriority(&ws.stream, hipStreamNonBlocking, least) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&ws.joined, hipEventDisableTiming) == hipSuccess;
+    ws.ok = good;
+  }
+  return ws;
+}
 static Ctx edge_ctx(const Ctx& c, hipStream_t edge) {       // same job list / slab cursor: host-side bookkeeping only
   Ctx x = c;
   x.s = edge;
   x.on_edge_stream = true;
+  x.wgrad = nullptr;
   x.y.bn_scratch = c.y.bn_scratch_e;
   x.y.col_stats = c.y.col_stats_e;
   return x;
@@ -281,7 +316,7 @@ static Ctx side_ctx(const Ctx& c, hipStream_t side) {
   x.s = side;
   x.y.bn_scratch = c.y.bn_scratch_x;
   x.y.dT1 = c.y.dT1x; x.y.dT2 = c.y.dT2x; x.y.slabs = c.y.slabs_x;
-  x.jobs = nullptr; x.slab_cursor = nullptr;
+  x.jobs = nullptr; x.slab_cursor = nullptr; x.wgrad = nullptr;
   return x;
 }
 
@@ -699,7 +734,11 @@ static int finish_pending(Pending& p) {
   return ESC_OK;
 }
 
-static int backward(const Ctx& c, Pending* defer) {
+static int backward(const Ctx& c_in, Pending* defer) {
+  Ctx c = c_in;
+  EdgeStream& es = edge_stream();
+  WgradStream& ws = wgrad_stream();
+  if (ws.ok && es.ok && c.jobs != nullptr && c.train && c.y.dT1_l[0] != nullptr) c.wgrad = ws.stream;
   const esc_nested_gin_t* m = c.m;
   const esc_batch_t* b = c.b;
   const Layout& y = c.y;
@@ -707,7 +746,6 @@ static int backward(const Ctx& c, Pending* defer) {
   // lin2 <- dpred
   ESC_TRY(linear_backward(c, y.dpred, 1, y.Yl, H, y.bl.scale, y.bl.shift, m->lin2, N, y.dAl, H, 0));
   // bn_lin1 backward: folded into lin1's backward when the fused kernels serve its column blocks (see g_bn_fuse_bwd)
-  EdgeStream& es = edge_stream();
   const bool split_lin1 = es.ok && c.jobs != nullptr && L >= 1;
   const esc_bn_bwd_fused fl = bn_fused(y.Yl, H, y.bl, 1);
   const bool fa_l = fuse_node_act(c);
@@ -737,6 +775,9 @@ static int backward(const Ctx& c, Pending* defer) {
       *c.slab_cursor += (esc_linear_bwd_weight_scratch(N, H, ncols) + 63) & ~63LL;
       c.jobs->emplace_back();
       const bool fa = fa_l;
+      Ctx cs = c;
+      if (stream != c.s) cs.wgrad = nullptr;
+      const WgradScope side(cs);
       if (fuse_l)
         return esc_linear_bwd_both_bn(y.dAl, H, &fl, y.cat + col0, W, fa ? y.cat_scale + col0 : nullptr, fa ? y.cat_shift + col0 : nullptr, m->lin1.w + col0, W,
                                       N, H, ncols, y.dcat + col0, W, 0, m->lin1.dw + col0, W, db, slabs, &c.jobs->back(), nx, stream);
@@ -787,7 +828,9 @@ static int backward(const Ctx& c, Pending* defer) {
     const int64_t C = l == 0 ? y.C0 : H;
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
-    ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W,
+    Ctx cl = c;
+    if (c.wgrad) { cl.y.dT1 = y.dT1_l[l]; cl.y.dT2 = y.dT2_l[l]; }     // still read by this layer's dW tiles when the next layer writes its own
+    ESC_TRY(mlp_backward(cl, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W,
                          y.dcat + (int64_t)(l + 1) * H, W, y.dagg, C, fuse_node_act(c), l == (int)L - 1 ? last_slots : agg_slots));
     agg_slots = 0;
     float* dx = l == 0 ? nullptr : y.dcat + (int64_t)l * H;            // accumulate into the previous slice
@@ -835,7 +878,11 @@ static int backward(const Ctx& c, Pending* defer) {
       edge_jobs.clear();                                                                    // once — its slabs wait for the final reduce)
     }
   }
-  if (!ss.ok) ESC_TRY(mlp_backward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0, fuse_node_act(c)));
+  if (!ss.ok) {
+    Ctx cx = c;
+    if (c.wgrad) { cx.y.dT1 = y.dT1x; cx.y.dT2 = y.dT2x; }
+    ESC_TRY(mlp_backward(cx, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, y.dcat, W, nullptr, 0, fuse_node_act(c)));
+  }
   // z_embedding + bag: the tail of the edge pipeline (d(z_emb) is complete in edge-stream order); it overlaps the
   // x_embedding backward queued above on the node stream
   const bool mat = g_materialise_edge_act != 0;
@@ -873,6 +920,7 @@ tail_bag:
   mark(PH_EDGE_BWD_DONE, ce.s);
   // node-side reductions first (with an edge stream they overlap its tail), then join, then the edge-side ones
   if (!eps_jobs.empty()) ESC_TRY(esc_reduce_sum_jobs(eps_jobs.data(), (int)eps_jobs.size(), c.s));
+  if (c.wgrad) ESC_TRY(chain(ws.joined, ws.stream, (hipStream_t)c.s));          // the slabs of the dW tiles that ran behind the chain
   if (c.jobs && !c.jobs->empty()) ESC_TRY(esc_slab_reduce_jobs(c.jobs->data(), (int)c.jobs->size(), c.s));
   if (ss.ok && hipStreamWaitEvent((hipStream_t)c.s, ss.join_b, 0) != hipSuccess) {
     set_error("esc_engine: side-stream join failed");

@@ -745,14 +745,14 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_kernel(GArgs g) {
 // Backward of one Linear in ONE launch: the first workgroups compute the dX tiles (NN), the rest the split-M dW slabs
 // (TN).  Both stream the same dY; one launch instead of two removes a boundary and lets the two under-filled grids
 // of the node-sized layers share the chip.
-struct DualArgs { GArgs dx, dw; int n_dx; };
+struct DualArgs { GArgs dx, dw; int n_dx; int b0; };   // b0: first job of this launch (a launch may carry only the dX or only the dW tiles)
 // BNB: dY is still the gradient of the BatchNorm(+ReLU) OUTPUT; its backward is applied to the operand as it is staged
 // (both jobs); BSTAT: the dX tiles also emit the column sums of the NEXT BatchNorm backward (see BnbDev / BnStatDev).
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO, bool BNB = false, bool BSTAT = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_dual_kernel(DualArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if constexpr (BM * BN < 128 * 128) ESC_PRIO();
-  const int b = (int)blockIdx.x;
+  const int b = (int)blockIdx.x + a.b0;
   if (b < a.n_dx) gemm_body<BM, BN, BK, WM, WN, STAGES, LW, false, true, (BNB ? 4 : 0) | (BSTAT ? 8 : 0), false, false>(a.dx, lds, b);
   else gemm_body<BM, BN, BK, WM, WN, STAGES, LW, true, true, (PRO ? 2 : 0) | (BNB ? 4 : 0), false, true>(a.dw, lds, b - a.n_dx);
 }
@@ -791,8 +791,10 @@ inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind
   return hipSuccess;
 }
 
+// s_dw: nullptr / s = one launch; another stream = the dX tiles on s and the dW tiles on s_dw (the caller has ordered s_dw
+// behind the operands' producers and keeps the operands untouched until s_dw has drained)
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool PRO, bool BNB = false, bool BSTAT = false>
-inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
+inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR, hipStream_t s_dw = nullptr) {
   using CX = Cfg<BM, BN, BK, WM, WN, STAGES, LW, false, true, (BNB ? 4 : 0) | (BSTAT ? 8 : 0), false, false>;
   using CW = Cfg<BM, BN, BK, WM, WN, STAGES, LW, true, true, (PRO ? 2 : 0) | (BNB ? 4 : 0), false, true>;
   auto kern = gemm_dual_kernel<BM, BN, BK, WM, WN, STAGES, LW, PRO, BNB, BSTAT>;
@@ -805,8 +807,16 @@ inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int k
   finish_args<BM, BN>(a.dx);
   finish_args<BM, BN>(a.dw);
   a.n_dx = a.dx.ntile_m * a.dx.ntile_n;
-  const unsigned nwg = (unsigned)(a.n_dx + a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw));
-  esc::launch(BM >= 128 && kind == ESC_K_LINEAR ? ESC_K_GEMM_EDGE : kind, kern, dim3(nwg), dim3(CX::NTHR), lds, s, a);
+  a.b0 = 0;
+  const unsigned n_dw = (unsigned)(a.dw.ntile_m * a.dw.ntile_n * splits_of(a.dw));
+  const int k = BM >= 128 && kind == ESC_K_LINEAR ? ESC_K_GEMM_EDGE : kind;
+  if (s_dw != nullptr && s_dw != s && a.n_dx > 0 && n_dw > 0) {
+    esc::launch(k, kern, dim3((unsigned)a.n_dx), dim3(CX::NTHR), lds, s, a);
+    a.b0 = a.n_dx;
+    esc::launch(k, kern, dim3(n_dw), dim3(CX::NTHR), lds, s_dw, a);
+    return hipSuccess;
+  }
+  esc::launch(k, kern, dim3((unsigned)a.n_dx + n_dw), dim3(CX::NTHR), lds, s, a);
   return hipSuccess;
 }
 

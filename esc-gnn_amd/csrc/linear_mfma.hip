@@ -21,7 +21,9 @@
 // dW).  LDS image [k][cols+4]; a lane reads single floats (ds_read_b32, consecutive lanes ->
 // consecutive banks).
 #include "common.h"
+#include <array>
 #include <cstdlib>
+#include <map>
 #include "gemm_dma.h"
 #include "linear_small.h"
 #include <type_traits>
@@ -1358,6 +1360,30 @@ static int weight_impl(const float* dY, int64_t ld_dy, const float* X, int64_t l
 
 }  // extern "C"
 
+// ---- weight-gradient tiles on a stream of their own (esc_linear_bwd_set_wgrad_stream) -------------------------------------
+// Inside a step the node chain waits for a Linear backward's dX only; its dW slabs are needed by the optimiser.  While a side
+// stream is set (thread-local), the node-sized dual launches with a DEFERRED slab reduce put their dW tiles there, ordered
+// behind everything queued on the launch stream so far (one event from a small per-device pool per launch).
+struct WgradSide {
+  hipStream_t stream = nullptr;
+  std::map<int, std::array<hipEvent_t, 16>> events;     // per device
+  int next = 0;
+};
+static thread_local WgradSide g_wside;
+static hipStream_t wgrad_stream_after(hipStream_t s) {
+  WgradSide& w = g_wside;
+  if (w.stream == nullptr || w.stream == s) return s;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return s;
+  auto it = w.events.find(dev);
+  if (it == w.events.end()) it = w.events.emplace(dev, std::array<hipEvent_t, 16>{}).first;
+  hipEvent_t& e = it->second[w.next];
+  w.next = (w.next + 1) & 15;
+  if (e == nullptr && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return s; }
+  if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(w.stream, e, 0) != hipSuccess) return s;
+  return w.stream;
+}
+
 template <int BM, int BN, int WM, int WN, int BK, bool PRO>
 static void launch_dual(const DualArgs& a, hipStream_t s) {
   constexpr int NTHR = WM * WN * 64;
@@ -1466,7 +1492,10 @@ static int both_impl(const float* dY, int64_t ld_dy, const float* X, int64_t ld_
                            : dma::launch_dual<128, 160, 32, 4, 1, 3, 4, false>(a, 0, s);
     else if (big) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true>(a, 0, s)
                           : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false>(a, 0, s);
-    else     e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false>(a, 0, s);
+    else {
+      hipStream_t sw = defer ? wgrad_stream_after(s) : s;
+      e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true>(a, 0, s, ESC_K_LINEAR, sw) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false>(a, 0, s, ESC_K_LINEAR, sw);
+    }
     if (dma_check(e, "esc_linear_bwd_both") != hipSuccess) return ESC_ELAUNCH;
     const int64_t n = N * K;
     if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, a.dw.db_part, N, db); return ESC_OK; }
@@ -1531,6 +1560,11 @@ static inline bool bnb_big_shape(int64_t M, int64_t N, int64_t K) { return M >= 
 static inline bool in_range_big(int64_t N) { return N <= 640; }
 static inline bool bnb_small_shape(int64_t N, int64_t K) { return (g_use_dma & 4) && K <= small::SMALL_MAX && N > small::SMALL_MAX && N % 4 == 0 && N <= 1024; }
 
+int esc_linear_bwd_set_wgrad_stream(void* stream) {
+  g_wside.stream = (hipStream_t)stream;
+  return ESC_OK;
+}
+
 int esc_linear_bwd_both_bn_ok(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
                               const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx,
                               const float* slabs, const esc_bn_bwd_next* next) {
@@ -1570,7 +1604,8 @@ int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_
     const int splits = (int)cdiv(M, small::ROWS_WGRAD);
     float* db_part = slabs + (size_t)splits * N * K;
     const dim3 grid((unsigned)splits, (unsigned)cdiv(N, 256));
-#define ESC_WG(PR, ACT) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, true, PR, ACT>, grid, dim3(256), 0, s, dOut, ld_dout, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, bd)
+    hipStream_t sw = defer ? wgrad_stream_after(s) : s;
+#define ESC_WG(PR, ACT) esc::launch(ESC_K_LINEAR, small::wgrad_small<small::SMALL_MAX, true, PR, ACT>, grid, dim3(256), 0, sw, dOut, ld_dout, X, ld_x, in_scale, in_shift, (int)M, (int)N, (int)K, slabs, db_part, bd)
     if (bd.relu == 2) { if (in_scale) ESC_WG(true, 2); else ESC_WG(false, 2); }
     else              { if (in_scale) ESC_WG(true, 1); else ESC_WG(false, 1); }
 #undef ESC_WG
@@ -1606,9 +1641,13 @@ int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_
   if (big) {
     if (next) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true, true, true>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false, true, true>(a, 0, s);
     else      e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true, true, false>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false, true, false>(a, 0, s);
-  } else if (bn == nullptr) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true, false, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false, false, true>(a, 0, s);
-  else if (next) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, true>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, true>(a, 0, s);
-  else      e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, false>(a, 0, s) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, false>(a, 0, s);
+  } else {
+    hipStream_t sw = defer ? wgrad_stream_after(s) : s;         // node-sized: the dW tiles may ride on the side stream
+    constexpr int KL = ESC_K_LINEAR;
+    if (bn == nullptr) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 3, 2, true, false, true>(a, 0, s, KL, sw) : dma::launch_dual<64, 64, 32, 2, 2, 3, 2, false, false, true>(a, 0, s, KL, sw);
+    else if (next) e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, true>(a, 0, s, KL, sw) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, true>(a, 0, s, KL, sw);
+    else      e = in_scale ? dma::launch_dual<64, 64, 32, 2, 2, 2, 2, true, true, false>(a, 0, s, KL, sw) : dma::launch_dual<64, 64, 32, 2, 2, 2, 2, false, true, false>(a, 0, s, KL, sw);
+  }
   if (dma_check(e, "esc_linear_bwd_both_bn") != hipSuccess) return ESC_ELAUNCH;
   if (defer) { fill_job(defer, slabs, n, splits, K, dW, ld_dw, a.dw.db_part, N, db); return ESC_OK; }
   esc::launch(ESC_K_LINEAR, slab_reduce_kernel, dim3((unsigned)cdiv(n + (db ? N : 0), 256)), dim3(256), 0, s, slabs, n,

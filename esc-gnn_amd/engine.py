@@ -115,11 +115,23 @@ def describe(m, gp=_grad_ptr):
     return d
 
 
-def _sync_groups(m):
-    return [mod.sync_group for mod in m.modules() if getattr(mod, "sync_group", False) is not False]
+def _bns(m, cache=None):
+    """the model's esc BatchNorm modules.  `cache`: a node cache the caller has just validated (engine_forward: a replaced
+    module brings new buffers, which invalidates it) — the per-step callers then skip the walk over ~200 submodules"""
+    if cache is None:
+        cache = m.__dict__.get("_esc_node_cache")
+        if cache is not None and not cache.valid():
+            cache = None
+    if cache is not None:
+        return cache.bns
+    return [mod for mod in m.modules() if hasattr(mod, "sync_group")]
 
 
-def engine_supports(m):
+def _sync_groups(m, cache=None):
+    return [mod.sync_group for mod in _bns(m, cache) if mod.sync_group is not False]
+
+
+def engine_supports(m, cache=None):
     """The configuration the whole-step engine covers: the run_graphcount one (reference :465).  BatchNorm statistics over
     several ranks (nn.BatchNorm1d.convert_sync) are served too: the engine exchanges them through a collective provider
     (install_collective below) — all BatchNorms of the model must then use the same process group."""
@@ -127,30 +139,31 @@ def engine_supports(m):
         return False
     if m.lin2.out_features != 1 or m.lin2.in_features % 4 != 0:
         return False
-    return _one_sync_group(m)
+    return _one_sync_group(m, cache)
 
 
-def _one_sync_group(m):
+def _one_sync_group(m, cache=None):
     """no SyncBN at all, or EVERY BatchNorm of the model on the same process group (the engines exchange all statistics
     through one collective provider)"""
-    groups = _sync_groups(m)
-    n_bn = sum(1 for mod in m.modules() if hasattr(mod, "sync_group"))
-    return not groups or (len(groups) == n_bn and all(g is groups[0] for g in groups))
+    bns = _bns(m, cache)
+    groups = [mod.sync_group for mod in bns if mod.sync_group is not False]
+    return not groups or (len(groups) == len(bns) and all(g is groups[0] for g in groups))
 
 
-def _bn_width(m):
+def _bn_width(m, cache=None):
     """widest BatchNorm of the model (the exchange buffers hold world * 3 * width floats)"""
-    return max([mod.num_features for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)] or [1])
+    mods = _bns(m, cache)
+    return max([mod.num_features for mod in mods if isinstance(mod, torch.nn.BatchNorm1d)] or [1])
 
 
-def _arm_collective(model, device):
+def _arm_collective(model, device, cache=None):
     """SyncBN models: (re)install the engines' all-reduce for the model's group; others: nothing to do"""
-    groups = _sync_groups(model)
+    groups = _sync_groups(model, cache)
     if not groups:
         return
-    if not _one_sync_group(model):
+    if not _one_sync_group(model, cache):
         raise NotImplementedError("step engine: all BatchNorm layers must share one sync group")
-    width = _bn_width(model)
+    width = _bn_width(model, cache)
     if _collective.get("group", False) is not groups[0] or _collective.get("width", 0) < width:
         install_collective(width, device, groups[0])
 
@@ -334,6 +347,7 @@ class _NodeCache(object):
         self.key = tuple(t.data_ptr() for t in self.params + self.buffers)
         self.counters = [m.num_batches_tracked for m in model.modules()
                          if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
+        self.bns = [m for m in model.modules() if hasattr(m, "sync_group")]     # see _bns
         index = {id(p): i for i, p in enumerate(self.params)}
         describe_fn = getattr(self, "_describe", describe)
         self.template = describe_fn(model, lambda p: self.MARK + index[id(p)])
@@ -364,19 +378,79 @@ class _NodeCache(object):
         np.frombuffer(d, dtype=np.uint64)[self.slots] = np.asarray(addresses, dtype=np.uint64)[self.slot_param]
         return d
 
-    def direct_bucket(self):
-        """the FlatAdam / FlatBucket that owns every parameter's .grad and is still clean (see
-        FlatBucket.direct_grad_addresses), as a list of gradient addresses — or None"""
+    def owning_bucket(self):
+        """the FlatAdam / FlatBucket that owns the parameters' .grad storage and lets the engines write into it, or None.  None
+        also when a parameter carries tensor hooks / post-accumulate hooks (DDP-style wrappers: they only fire on gradients
+        that come back through autograd) or does not require a gradient."""
         from .parallel import _BUCKETS
         g0 = self.params[0].grad
         base = getattr(g0, "_base", None) if g0 is not None else None
         bucket = _BUCKETS.get(base.data_ptr()) if base is not None else None
-        if bucket is None:
+        if bucket is None or not bucket.engine_direct:
             return None
-        for p in self.params:          # tensor hooks / post-accumulate hooks (DDP-style wrappers) only fire on returned gradients
-            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+        for p in self.params:
+            if not p.requires_grad or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
                 return None
-        return bucket.direct_grad_addresses(self.params)
+        return bucket
+
+    def direct_bucket(self):
+        """owning_bucket() that is moreover still clean (see FlatBucket.direct_grad_addresses), as a list of gradient
+        addresses — or None"""
+        bucket = self.owning_bucket()
+        return bucket.direct_grad_addresses(self.params) if bucket is not None else None
+
+    def node_inputs(self):
+        """The differentiable inputs of the engine's autograd node.  Normally every parameter (their gradients come back
+        through autograd).  When a FlatAdam / FlatBucket owns every .grad, only the FIRST parameter: the backward writes
+        (clean bucket) or adds (otherwise) the gradients into the bucket itself and returns none, so the graph carries one
+        edge instead of one AccumulateGrad per parameter — 104 of them cost the reference's loop ~0.25 ms of host time per
+        step (tools/measure/dropin_prof.py).  torch.autograd.grad(loss, parameters) does not see such a node's gradients."""
+        return (self.params[0],) if self.owning_bucket() is not None else tuple(self.params)
+
+
+def _node_backward(ctx, dpred, entry):
+    """backward of the three engine nodes: gradients straight into a clean FlatAdam bucket, else returned (or, for a
+    node built on node_inputs()' short form, added into the bucket / the .grad tensors by hand)"""
+    cache = ctx.cache
+    if ctx.ws is None:
+        raise RuntimeError("esc_gnn_amd: this engine node's workspace was released by its first backward; a second "
+                           "backward through the same forward (retain_graph=True) needs the per-op path")
+    g = dpred.reshape(-1)
+    g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+    slim = ctx.n_in < len(cache.params)
+    none = (None, None, None) + (None,) * ctx.n_in
+
+    def run(desc):
+        nv.call(entry, ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+        ctx.ws = ctx.keep = None
+
+    bucket = cache.owning_bucket()
+    direct = bucket.direct_grad_addresses(cache.params) if bucket is not None else None
+    if direct is not None:             # every .grad is a clean FlatAdam bucket view: write there, nothing to accumulate
+        run(cache.descriptor_at(direct))
+        return none
+    if slim:
+        # the bucket has been written since its zero_grad() (a second backward before the optimiser step): accumulate
+        offs = bucket.grad_offsets(cache.params) if bucket is not None else None
+        if offs is not None:           # ... in one pass over a scratch copy with the bucket's own layout
+            tmp = torch.zeros_like(bucket.flat_grad)
+            run(cache.descriptor_at([tmp.data_ptr() + 4 * o for o in offs]))
+            bucket.flat_grad.add_(tmp)
+            return none
+        flat = torch.zeros(cache.total, dtype=torch.float32, device=dpred.device)    # .grad was re-bound by the caller
+        run(cache.descriptor(flat.data_ptr()))
+        for p, o in zip(cache.params, cache.offsets):
+            gp = flat[o:o + p.numel()].view(p.shape)
+            if p.grad is None:
+                p.grad = gp
+            else:
+                p.grad.add_(gp)
+        return none
+    flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
+    run(cache.descriptor(flat.data_ptr()))
+    grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
+                  for p, o in zip(cache.params, cache.offsets))
+    return (None, None, None) + grads
 
 
 def _node_cache(model):
@@ -404,31 +478,13 @@ class _EngineNode(torch.autograd.Function):
         nv.call("esc_engine_forward_train", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
         if cache.counters:
             torch._foreach_add_(cache.counters, 1)
-        ctx.cache, ctx.b, ctx.keep, ctx.ws = cache, b, keep, ws
+        ctx.cache, ctx.b, ctx.keep, ctx.ws, ctx.n_in = cache, b, keep, ws, len(params)
         return pred.view(-1, 1)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
-        cache = ctx.cache
-        if ctx.ws is None:
-            raise RuntimeError("esc_gnn_amd: this engine node's workspace was released by its first backward; a second "
-                               "backward through the same forward (retain_graph=True) needs the per-op path")
-        g = dpred.reshape(-1)
-        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
-        direct = cache.direct_bucket()
-        if direct is not None:             # every .grad is a clean FlatAdam bucket view: write there, nothing to accumulate
-            desc = cache.descriptor_at(direct)
-            nv.call("esc_engine_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
-            ctx.ws = ctx.keep = None
-            return (None, None, None) + (None,) * len(cache.params)
-        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
-        desc = cache.descriptor(flat.data_ptr())
-        nv.call("esc_engine_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
-        grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
-                      for p, o in zip(cache.params, cache.offsets))
-        ctx.ws = ctx.keep = None
-        return (None, None, None) + grads
+        return _node_backward(ctx, dpred, "esc_engine_backward")
 
 
 @torch.no_grad()
@@ -445,10 +501,10 @@ def engine_predict(model, data):
     return pred.view(-1, 1)
 
 
-def engine_forward(model, data):
-    _arm_collective(model, model.lin1.weight.device)         # SyncBN: the engine needs its all-reduce
-    cache = _node_cache(model)
-    return _EngineNode.apply(model, data, cache, *cache.params)
+def engine_forward(model, data, cache=None):
+    cache = cache if cache is not None else _node_cache(model)
+    _arm_collective(model, model.lin1.weight.device, cache)  # SyncBN: the engine needs its all-reduce
+    return _EngineNode.apply(model, data, cache, *cache.node_inputs())
 
 
 # ---- ZINC variant (zinc_models.NestedGIN_eff; csrc/engine.hip esc_zinc_*) ---------------------------------------------
@@ -620,31 +676,13 @@ class _ZincEngineNode(torch.autograd.Function):
         nv.call("esc_zinc_forward_train", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
         if cache.counters:
             torch._foreach_add_(cache.counters, 1)
-        ctx.cache, ctx.b, ctx.keep, ctx.ws = cache, b, keep, ws
+        ctx.cache, ctx.b, ctx.keep, ctx.ws, ctx.n_in = cache, b, keep, ws, len(params)
         return pred.view(-1, 1)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
-        cache = ctx.cache
-        if ctx.ws is None:
-            raise RuntimeError("esc_gnn_amd: this engine node's workspace was released by its first backward; a second "
-                               "backward through the same forward (retain_graph=True) needs the per-op path")
-        g = dpred.reshape(-1)
-        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
-        direct = cache.direct_bucket()
-        if direct is not None:             # every .grad is a clean FlatAdam bucket view: write there, nothing to accumulate
-            desc = cache.descriptor_at(direct)
-            nv.call("esc_zinc_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
-            ctx.ws = ctx.keep = None
-            return (None, None, None) + (None,) * len(cache.params)
-        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
-        desc = cache.descriptor(flat.data_ptr())
-        nv.call("esc_zinc_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
-        grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
-                      for p, o in zip(cache.params, cache.offsets))
-        ctx.ws = ctx.keep = None
-        return (None, None, None) + grads
+        return _node_backward(ctx, dpred, "esc_zinc_backward")
 
 
 def _mol_cache(model, kind):
@@ -670,12 +708,12 @@ def zinc_engine_predict(model, data):
 
 
 def zinc_engine_forward(model, data):
-    _arm_collective(model, model.lin1.weight.device)
     c = model.__dict__.get("_esc_node_cache")
     if c is None or not c.valid():
         c = _ZincNodeCache(model)
         model.__dict__["_esc_node_cache"] = c
-    return _ZincEngineNode.apply(model, data, c, *c.params)
+    _arm_collective(model, model.lin1.weight.device, c)
+    return _ZincEngineNode.apply(model, data, c, *c.node_inputs())
 
 
 # ---- OGB molecule variant (ogb_mol_gnn.GNN(gnn_type="gin_eff"); csrc/engine.hip esc_ogb_*) -----------------------------
@@ -909,31 +947,13 @@ class _OgbEngineNode(torch.autograd.Function):
         nv.call("esc_ogb_forward_train", ctypes.byref(desc), ctypes.byref(b), ws.data_ptr(), pred.data_ptr(), nv.stream())
         if cache.counters:
             torch._foreach_add_(cache.counters, 1)
-        ctx.cache, ctx.b, ctx.keep, ctx.ws = cache, b, keep, ws
+        ctx.cache, ctx.b, ctx.keep, ctx.ws, ctx.n_in = cache, b, keep, ws, len(params)
         return pred
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dpred):
-        cache = ctx.cache
-        if ctx.ws is None:
-            raise RuntimeError("esc_gnn_amd: this engine node's workspace was released by its first backward; a second "
-                               "backward through the same forward (retain_graph=True) needs the per-op path")
-        g = dpred.reshape(-1)
-        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
-        direct = cache.direct_bucket()
-        if direct is not None:             # every .grad is a clean FlatAdam bucket view: write there, nothing to accumulate
-            desc = cache.descriptor_at(direct)
-            nv.call("esc_ogb_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
-            ctx.ws = ctx.keep = None
-            return (None, None, None) + (None,) * len(cache.params)
-        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)   # fresh: the views alias nothing older
-        desc = cache.descriptor(flat.data_ptr())
-        nv.call("esc_ogb_backward", ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
-        grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
-                      for p, o in zip(cache.params, cache.offsets))
-        ctx.ws = ctx.keep = None
-        return (None, None, None) + grads
+        return _node_backward(ctx, dpred, "esc_ogb_backward")
 
 
 @torch.no_grad()
@@ -951,9 +971,9 @@ def ogb_engine_predict(model, data):
 
 
 def ogb_engine_forward(model, data):
-    _arm_collective(model, model.graph_pred_linear.weight.device)
     c = model.__dict__.get("_esc_node_cache")
     if c is None or not c.valid():
         c = _OgbNodeCache(model)
         model.__dict__["_esc_node_cache"] = c
-    return _OgbEngineNode.apply(model, data, c, *c.params)
+    _arm_collective(model, model.graph_pred_linear.weight.device, c)
+    return _OgbEngineNode.apply(model, data, c, *c.node_inputs())

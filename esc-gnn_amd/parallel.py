@@ -124,6 +124,18 @@ class FlatBucket(object):
         self._clean_version = None                         # (the raw write does not move torch's version counter)
         return out
 
+    def grad_offsets(self, params):
+        """float offsets of the gradient slots of `params` inside flat_grad if every .grad still is this bucket's view
+        (the engine node's backward then accumulates a second backward's gradients with ONE add over a scratch copy of the
+        same layout); None otherwise"""
+        base, out = self.flat_grad.data_ptr(), []
+        for p in params:
+            off = self._offset_of.get(id(p))
+            if off is None or p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                return None
+            out.append(off)
+        return out
+
     def all_reduce_weighted(self, n_local, group=None):
         """grad <- sum_r n_r * grad_r / sum_r n_r   with one SUM all-reduce."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

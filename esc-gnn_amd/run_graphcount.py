@@ -66,9 +66,10 @@ class NestedGIN_eff(torch.nn.Module):
         if (self.training and torch.is_grad_enabled() and not return_embeddings and self.engine_forward
                 and "edge_pos" not in data and x.is_floating_point() and x.dim() == 2 and x.size(0) >= 2
                 and edge_index.size(1) >= 2 and "pos_batch" in data):       # the engine's own preconditions (esc::check)
-            from .engine import engine_forward, engine_supports
-            if engine_supports(self) and x.size(1) == self.x_embedding[0].in_features:
-                return engine_forward(self, data)       # the whole step as one autograd node (engine.hip)
+            from .engine import MAX_LAYERS, engine_forward, engine_supports, _node_cache
+            cache = _node_cache(self) if self.lin1.weight.device.type == "cuda" and 1 + len(self.convs) <= MAX_LAYERS else None
+            if engine_supports(self, cache) and x.size(1) == self.x_embedding[0].in_features:
+                return engine_forward(self, data, cache)       # the whole step as one autograd node (engine.hip)
         if (not self.training and not torch.is_grad_enabled() and not return_embeddings and self.engine_forward
                 and "edge_pos" not in data and x.is_floating_point() and x.dim() == 2 and x.size(0) >= 2
                 and edge_index.size(1) >= 2 and "pos_batch" in data):

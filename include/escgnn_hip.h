@@ -301,6 +301,16 @@ int esc_linear_bwd_both_bn_ok(const float* dOut, int64_t ld_dout, const esc_bn_b
                               const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, const float* dX, int64_t ld_dx,
                               const float* slabs, const esc_bn_bwd_next* next);
 int64_t esc_linear_bwd_bn_block_rows(int64_t M, int64_t N, int64_t K);
+
+/* Weight-gradient tiles on a stream of their own (thread-local setting; NULL = off, the default).
+ * Inside a training step the dependent chain waits for a Linear backward's dX only (the reference's autograd has the same
+ * dependency structure: torch.nn.Linear's grad_weight feeds nothing but the optimiser, run_graphcount.py:497-505).  While
+ * `stream` is set, the node-sized (64-row tile) launches of esc_linear_bwd_both_deferred / esc_linear_bwd_both_bn whose slab
+ * reduce is DEFERRED (job != NULL) enqueue their dW tiles on `stream`, ordered behind everything queued so far on the launch
+ * stream; the dX tiles stay where they were.  The caller (a) keeps dY / X / the BatchNorm operands of such a call unchanged
+ * until `stream` has drained, and (b) orders esc_slab_reduce_jobs behind `stream`.  Results are bit-identical to the single
+ * launch (same tiles, same slabs, same ordered reduce).  The step engine turns it on with ESC_WGRAD_STREAM=1. */
+int esc_linear_bwd_set_wgrad_stream(void* stream);
 int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_fused* bn, const float* X, int64_t ld_x,
                            const float* in_scale, const float* in_shift, const float* W, int64_t ld_w, int64_t M,
                            int64_t N, int64_t K, float* dX, int64_t ld_dx, int accumulate, float* dW, int64_t ld_dw,

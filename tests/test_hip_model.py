@@ -582,7 +582,8 @@ def test_engine_node_writes_into_a_clean_flatadam_bucket():
         opt = E.optim.FlatAdam(m2.parameters(), lr=1e-3) if not extra else opt      # noqa: F821  (same bucket both rounds)
         opt.zero_grad()
         loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
-        assert opt._clean_version is None                                   # the direct path was taken
+        if not extra:          # (with the extra terms autograd may add their share first: the node then adds onto it)
+            assert opt._clean_version is None                               # the direct path was taken
         for n, p in m2.named_parameters():
             assert p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * opt._offset_of[id(p)], n
             _close(p.grad, want[n].cpu(), "direct grad " + n, tol=2e-5)
@@ -597,6 +598,20 @@ def test_engine_node_writes_into_a_clean_flatadam_bucket():
         for n, p in m2.named_parameters():
             _close(p.grad, want[n].cpu(), "accumulate-path grad " + n, tol=2e-5)
         opt.engine_direct = True
+        # a .grad re-bound by the caller between zero_grad and backward: the node (built on the short input form, see below)
+        # adds into whatever .grad is now
+        opt.zero_grad()
+        m2.lin2.weight.grad = torch.zeros_like(m2.lin2.weight)
+        loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
+        for n, p in m2.named_parameters():
+            _close(p.grad, want[n].cpu(), "re-bound grad " + n, tol=2e-5)
+    # with a bucket that owns every .grad the node takes ONE parameter as its differentiable input (no AccumulateGrad edge per
+    # parameter); without one, all of them
+    opt.zero_grad()
+    n_par = len(list(m2.parameters()))
+    assert len(m2(E.Data(**{k: v.clone() for k, v in bt.items()})).grad_fn.next_functions) == 1
+    opt.engine_direct = False
+    assert len(m2(E.Data(**{k: v.clone() for k, v in bt.items()})).grad_fn.next_functions) == n_par
 
 
 def test_ogb_engine_trusts_store_features_only_while_untouched():
