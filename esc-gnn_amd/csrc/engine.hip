@@ -249,7 +249,7 @@ static EdgeStream& edge_stream() {
   }
   return es;
 }
-// The molecule engines use the second stream only when the batch has enough edges for the edge-sized kernels to matter:
+// The engines use the second stream only when the batch has enough edges for the edge-sized kernels to matter:
 // ZINC at bs=128 (6 400 edges) measured 1.24 ms on one stream and 1.35 ms on two (the events cost more than the overlap
 // returns); ogbg-molhiv at bs=256 (20 000 edges, emb 300) 5.44 -> 5.18 ms.
 static int64_t g_two_stream_min_edges = 12000;       // esc_engine_set_two_stream_min_edges()
@@ -608,8 +608,11 @@ static int forward(const Ctx& c) {
   const Layout& y = c.y;
   const int64_t N = y.N, E = y.E, H = y.H, L = y.L, W = y.W;
   // ---- edge pipeline: ESC bag, z_embedding (reference :155-156) and the edge terms e_l = lin_l(z_emb) of ALL layers
-  // (:161,:169 inside GINEConv).  It touches the node chain only through e_l, so it runs on the edge stream.
-  EdgeStream& es = edge_stream();
+  // (:161,:169 inside GINEConv).  It touches the node chain only through e_l, so it runs on the edge stream — for batches of at
+  // least g_two_stream_min_edges edges: below that (the per-rank slices of a strong-scaling run: 16 graphs, 1 900 edges) the
+  // edge-sized kernels are as latency-bound as the node chain and the events cost more than the overlap returns (bs 16: 0.68 ms on
+  // one stream, 0.84 on two; bs 64: 0.85 / 0.89; bs 128: 1.25 / 1.04).
+  EdgeStream& es = edge_stream_for(E);
   Ctx ce = c;
   if (es.ok) {
     ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));       // the batch arrays were produced on the caller's stream
@@ -736,7 +739,7 @@ static int finish_pending(Pending& p) {
 
 static int backward(const Ctx& c_in, Pending* defer) {
   Ctx c = c_in;
-  EdgeStream& es = edge_stream();
+  EdgeStream& es = edge_stream_for(c.y.E);
   WgradStream& ws = wgrad_stream();
   if (ws.ok && es.ok && c.jobs != nullptr && c.train && c.y.dT1_l[0] != nullptr) c.wgrad = ws.stream;
   const esc_nested_gin_t* m = c.m;

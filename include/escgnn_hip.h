@@ -443,7 +443,10 @@ typedef struct esc_batch_t {
  * bit 1 (default on): the edge-sized conv.lin GEMMs of all layers run on a second HIP stream, ordered against the
  * node chain by one event per dependency; bit 0 (default off): the x_embedding branch on a further stream.  Default 2. */
 int esc_engine_set_side_stream(int on);
-/* esc_zinc_* / esc_ogb_*: smallest batch (in edges) whose edge pipeline runs on the second stream (default 12 000; 0 = always) */
+/* all three engines: smallest batch (in edges) whose edge pipeline runs on the second stream (default 12 000; 0 = always).
+ * Smaller batches — ZINC at bs 128, the 16-graph per-rank slices of a strong-scaling run of the counting model — are launch-latency
+ * bound on both pipelines and the cross-stream events cost more than the overlap returns (counting model, bs 16: 0.68 ms on one
+ * stream, 0.84 ms on two). */
 int esc_engine_set_two_stream_min_edges(int64_t edges);
 /* 1 (default): write relu(BN(.)) of the two EDGE-sized z_embedding activations once instead of re-applying the
  * affine+ReLU prologue in every consumer GEMM; 0: fully fused (less memory, slower on MI355X r01). */

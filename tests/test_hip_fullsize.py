@@ -341,9 +341,19 @@ def test_split_step_equals_single_call(E, world):
     assert bool(torch.isfinite(pred).all())
 
 
+@pytest.fixture(params=[0, 12000], ids=["two_streams", "one_stream"])
+def count_streams(request):
+    """the engines put the edge pipeline on a second stream for batches of >= 12 000 edges (the default; the small batches
+    of this file then run on one stream, as the per-rank slices of a strong-scaling run do); 0 forces two streams"""
+    from esc_gnn_amd import _native as nv
+    nv.call("esc_engine_set_two_stream_min_edges", request.param)
+    yield request.param
+    nv.call("esc_engine_set_two_stream_min_edges", 12000)
+
+
 @pytest.mark.parametrize("L,H,bs", [(1, 32, 3), (2, 64, 17), (5, 256, 40), (3, 128, 2)])
-def test_engine_matches_autograd_over_shapes(E, L, H, bs):
-    """The two-stream engine against the per-op autograd path over layer counts / widths / batch sizes the fixed
+def test_engine_matches_autograd_over_shapes(E, count_streams, L, H, bs):
+    """The engine (two streams / one) against the per-op autograd path over layer counts / widths / batch sizes the fixed
     BASELINE shapes do not exercise (L=1: no hidden GINE layer; L=5: the reference's default depth; tiny batches)."""
     from esc_gnn_amd.datasets import build_count_dataset
     import copy
