@@ -9,6 +9,7 @@ compact execution plan.  The sorted per-graph views the plan needs are derived o
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _native as nv
@@ -180,10 +181,16 @@ class DeviceGraphStore(object):
             raise ValueError("collate: empty batch")
         if int(ids_h.min()) < 0 or int(ids_h.max()) >= self.num_graphs:
             raise IndexError("collate: graph id out of range")
+        # (numpy on the host pointers: the same arithmetic through torch costs ~5x the host time, and the loop is host-bound
+        # on some boxes)
+        ptrs = self.__dict__.get("_np_ptrs")
+        if ptrs is None:
+            ptrs = np.stack([t.numpy() for t in (self.h_node_ptr, self.h_edge_ptr, self.h_nnz_ptr, self.h_y_ptr)])
+            self.__dict__["_np_ptrs"] = ptrs
         offs = torch.zeros(4, B + 1, dtype=torch.int64, pin_memory=True)
-        for r, p in enumerate((self.h_node_ptr, self.h_edge_ptr, self.h_nnz_ptr, self.h_y_ptr)):
-            offs[r, 1:] = torch.cumsum(p[ids_h + 1] - p[ids_h], 0)
-        N, E, Z, Y = (int(offs[r, B]) for r in range(4))
+        idn = ids_h.numpy()
+        np.cumsum(ptrs[:, idn + 1] - ptrs[:, idn], axis=1, out=offs.numpy()[:, 1:])
+        N, E, Z, Y = (int(v) for v in offs.numpy()[:, B])
         offs_d = offs.to(self.device, non_blocking=True)
         dev, i64, i32, f32 = self.device, torch.int64, torch.int32, torch.float32
         # categorical node features (ZINC / OGB) leave the fill kernel as int64; per-edge attribute rows are gathered by it too
@@ -213,23 +220,27 @@ class DeviceGraphStore(object):
         s = nv.stream()
         nv.call("esc_collate_cols", nv.ptr(self.col_cnt_all), N_COLS, nv.ptr(ids_d), B, nv.ptr(col_prefix),
                 nv.ptr(col_total), nv.ptr(col_ptr), s)
-        a = nv.CollateArgs()
-        a.B, a.x_dim, a.y_dim, a.n_cols = B, self.x_dim, self.y_dim, N_COLS
-        for name, t in (("graph_ids", ids_d), ("offsets", offs_d), ("node_ptr", self.node_ptr),
-                        ("edge_ptr", self.edge_ptr), ("nnz_ptr", self.nnz_ptr), ("y_ptr", self.y_ptr),
-                        ("x_all", self.x_all), ("y_all", self.y_all), ("esrc_all", self.esrc_all),
-                        ("edst_all", self.edst_all), ("pos_enc_all", self.pos_enc_all),
-                        ("pos_index_all", self.pos_index_all), ("pos_batch_all", self.pos_batch_all),
-                        ("in_ptr_all", self.in_ptr_all), ("in_edge_all", self.in_edge_all),
-                        ("out_ptr_all", self.out_ptr_all), ("out_edge_all", self.out_edge_all),
-                        ("row_ptr_all", self.row_ptr_all), ("c_perm_all", self.c_perm_all),
-                        ("c_rank_all", self.c_rank_all), ("col_ptr", col_ptr), ("col_prefix", col_prefix),
-                        ("x", x), ("y", y), ("edge_index", edge_index), ("batch", batch), ("pos_enc", pos_enc),
-                        ("pos_index", pos_index), ("pos_batch", pos_batch), ("in_ptr", in_ptr),
-                        ("in_edge", in_edge), ("in_src", in_src), ("out_ptr", out_ptr), ("out_edge", out_edge),
-                        ("out_dst", out_dst), ("row_ptr", row_ptr), ("bag_idx", bag_idx), ("bag_val", bag_val),
-                        ("col_row", col_row), ("col_val", col_val), ("col_col", col_col)):
-            setattr(a, name, t.data_ptr())
+        tpl = self.__dict__.get("_args_tpl")
+        if tpl is None:                 # the store's own arrays never move: their addresses are filled in once
+            t0 = nv.CollateArgs()
+            t0.x_dim, t0.y_dim, t0.n_cols = self.x_dim, self.y_dim, N_COLS
+            for name in ("node_ptr", "edge_ptr", "nnz_ptr", "y_ptr", "x_all", "y_all", "esrc_all", "edst_all", "pos_enc_all",
+                         "pos_index_all", "pos_batch_all", "in_ptr_all", "in_edge_all", "out_ptr_all", "out_edge_all",
+                         "row_ptr_all", "c_perm_all", "c_rank_all"):
+                setattr(t0, name, getattr(self, name).data_ptr())
+            tpl = bytes(t0)
+            self.__dict__["_args_tpl"] = tpl
+        a = nv.CollateArgs.from_buffer_copy(tpl)
+        a.B = B
+        a.graph_ids, a.offsets, a.col_ptr, a.col_prefix = ids_d.data_ptr(), offs_d.data_ptr(), col_ptr.data_ptr(), col_prefix.data_ptr()
+        a.x, a.y, a.edge_index, a.batch = x.data_ptr(), y.data_ptr(), edge_index.data_ptr(), batch.data_ptr()
+        a.pos_enc, a.pos_index, a.pos_batch = pos_enc.data_ptr(), pos_index.data_ptr(), pos_batch.data_ptr()
+        base32 = slab.data_ptr()        # the plan arrays are consecutive int32 ranges of one slab
+        o = 0
+        for name, s_ in zip(("in_ptr", "in_edge", "in_src", "out_ptr", "out_edge", "out_dst", "row_ptr", "bag_idx", "bag_val",
+                             "col_row", "col_val", "col_col"), sizes):
+            setattr(a, name, base32 + 4 * o)
+            o += s_
         if self.x_is_int:
             a.x, a.x_long = None, x.data_ptr()
         if ea_fused:

@@ -5,7 +5,7 @@ sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(
 import esc_gnn_amd as E
 from esc_gnn_amd.datasets import build_count_dataset
 DEV = 'cuda:0'
-bs = 128
+bs = int(os.environ.get("ESC_BS", "128"))
 graphs = build_count_dataset(0, 4 * bs, h=3, use_rd=True, self_loop=True)
 y = torch.cat([g.y.view(-1) for g in graphs])
 for g in graphs:
