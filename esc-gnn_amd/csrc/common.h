@@ -99,6 +99,8 @@ unsigned* tickets(int n);
 int gemm_lds_floor();
 void set_gemm_lds_floor(int bytes);
 int edge_lds_floor();
+int node_lds_floor();          // least dynamic LDS of the 64-row tile launches (bytes): set by the step engine around its node chain
+void set_node_lds_floor(int bytes);
 void set_edge_lds_floor(int bytes);
 int norm_rowblock_cap();              // workgroups per column block of the BatchNorm reduction kernels (esc_tune_set(9, v))
 void set_norm_rowblock_cap(int v);

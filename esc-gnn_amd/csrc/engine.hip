@@ -14,6 +14,7 @@
 // use_cycle=True — the configuration run_graphcount.py:465 instantiates).
 #include "common.h"
 
+#include <cstring>
 #include <map>
 #include <vector>
 #include <cstdlib>
@@ -151,6 +152,20 @@ struct LdsFloorGuard {            // occupancy cap for the GEMMs launched while 
   bool on_;
 };
 
+// Where the node chain's GEMM workgroups land.  An edge-stream GEMM (128x128 tile, 96 KB of LDS, one workgroup per CU) leaves 64 KB
+// of its CU's LDS free, so a 54-KB node workgroup co-resides with it and the two share the CU's MFMA pipe.  A node workgroup that
+// ASKS for 66 KB (dynamic LDS it does not use) is only placed on CUs without an edge workgroup: in the backward — dual launches of 392
+// workgroups beside 57-us edge launches of 478 — that is worth 15 us of the node chain (phase marks: node backward 477 -> 462 us,
+// step 0.995 -> 0.980 ms; bench 1.048 -> 1.031 ms); 60 000 bytes (still co-resident) changes nothing, 82 000 (one node workgroup per
+// CU) costs 50 us, and in the forward (152-workgroup launches) the same request costs 8 us.  ESC_NODE_LDS_FLOOR_FWD / _BWD, bytes.
+static int g_node_floor_fwd = getenv("ESC_NODE_LDS_FLOOR_FWD") ? atoi(getenv("ESC_NODE_LDS_FLOOR_FWD")) : 0;
+static int g_node_floor_bwd = getenv("ESC_NODE_LDS_FLOOR_BWD") ? atoi(getenv("ESC_NODE_LDS_FLOOR_BWD")) : 66 * 1024;
+struct NodeFloorGuard {
+  explicit NodeFloorGuard(int bytes) : on_(bytes > 0) { if (on_) set_node_lds_floor(bytes); }
+  ~NodeFloorGuard() { if (on_) set_node_lds_floor(0); }
+  bool on_;
+};
+
 static int linear_backward(const Ctx& c, const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, const float* sc,
                            const float* sh, const esc_linear_t& lin, int64_t M, float* dX, int64_t ld_dx, int accumulate) {
   const LdsFloorGuard cap(c.on_edge_stream);
@@ -234,7 +249,20 @@ static EdgeStream& edge_stream() {
     // lowest priority: when workgroup slots free up, the latency-critical node chain is served first
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    bool good = hipStreamCreateWithPriority(&es.stream, hipStreamNonBlocking, g_edge_priority_low ? least : greatest) == hipSuccess;
+    // ESC_EDGE_CU_MASK (experiment, DESIGN.md *Step engine, r03* (vi)): the edge stream on a subset of the CUs.  "low:N" = the first N
+    // mask bits (the driver deals mask bits round-robin over the 8 XCDs: N/8 CUs of every XCD), "xcd:K" = the CUs of XCDs 0..K-1.
+    bool good = false;
+    if (const char* mk = getenv("ESC_EDGE_CU_MASK")) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int n = atoi(strchr(mk, ':') ? strchr(mk, ':') + 1 : "0");
+      for (int i = 0; i < 256; ++i) {
+        const bool on = strncmp(mk, "xcd", 3) == 0 ? (i % 8) < n : i < n;
+        if (on) mask[i / 32] |= 1u << (i % 32);
+      }
+      good = n > 0 && hipExtStreamCreateWithCUMask(&es.stream, 8, mask) == hipSuccess;
+    } else {
+      good = hipStreamCreateWithPriority(&es.stream, hipStreamNonBlocking, g_edge_priority_low ? least : greatest) == hipSuccess;
+    }
     good = good && hipEventCreateWithFlags(&es.z_ready, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&es.joined, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&es.lin1_fork, hipEventDisableTiming) == hipSuccess;
@@ -613,6 +641,7 @@ static int forward(const Ctx& c) {
   // edge-sized kernels are as latency-bound as the node chain and the events cost more than the overlap returns (bs 16: 0.68 ms on
   // one stream, 0.84 on two; bs 64: 0.85 / 0.89; bs 128: 1.25 / 1.04).
   EdgeStream& es = edge_stream_for(E);
+  const NodeFloorGuard node_floor(es.ok && c.train ? g_node_floor_fwd : 0);
   Ctx ce = c;
   if (es.ok) {
     ESC_TRY(chain(es.z_ready, (hipStream_t)c.s, es.stream));       // the batch arrays were produced on the caller's stream
@@ -740,6 +769,7 @@ static int finish_pending(Pending& p) {
 static int backward(const Ctx& c_in, Pending* defer) {
   Ctx c = c_in;
   EdgeStream& es = edge_stream_for(c.y.E);
+  const NodeFloorGuard node_floor(es.ok ? g_node_floor_bwd : 0);
   WgradStream& ws = wgrad_stream();
   if (ws.ok && es.ok && c.jobs != nullptr && c.train && c.y.dT1_l[0] != nullptr) c.wgrad = ws.stream;
   const esc_nested_gin_t* m = c.m;

@@ -1637,7 +1637,8 @@ int esc_linear_bwd_both_bn(const float* dOut, int64_t ld_dout, const esc_bn_bwd_
     a.dx.bst = BnStatDev{reinterpret_cast<float2*>(next->partial), next->x, (int)next->ld_x, next->mean, next->invstd, next->scale, next->shift, next->relu};
   hipError_t e;
   // (the third operand image of the fused apply costs a ring stage: two stages keep the workgroup at 54 KB, which fits beside
-  // an edge-stream GEMM on a CU; three stages — 78 KB — measured slower inside the two-stream step)
+  // an edge-stream GEMM on a CU; three stages — 78 KB — measured slower inside the two-stream step, and neutral (0.988 vs 0.985 ms)
+  // once the backward's node workgroups keep off the edge GEMMs' CUs altogether)
   if (big) {
     if (next) e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true, true, true>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false, true, true>(a, 0, s);
     else      e = in_scale ? dma::launch_dual<128, 128, 32, 2, 2, 3, 4, true, true, false>(a, 0, s) : dma::launch_dual<128, 128, 32, 2, 2, 3, 4, false, true, false>(a, 0, s);

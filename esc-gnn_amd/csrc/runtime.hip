@@ -56,6 +56,9 @@ int gemm_lds_floor() { return g_gemm_lds_floor; }
 void set_gemm_lds_floor(int bytes) { g_gemm_lds_floor = bytes < 0 ? 0 : (bytes > 160 * 1024 ? 160 * 1024 : bytes); }
 static int g_edge_lds_floor = 52 * 1024;      // 3 edge-GEMM workgroups per CU: a wave slot per SIMD stays free for the node stream
 int edge_lds_floor() { return g_edge_lds_floor; }
+static thread_local int g_node_lds_floor = 0;
+int node_lds_floor() { return g_node_lds_floor; }
+void set_node_lds_floor(int bytes) { g_node_lds_floor = bytes < 0 ? 0 : (bytes > 160 * 1024 ? 160 * 1024 : bytes); }
 void set_edge_lds_floor(int bytes) { g_edge_lds_floor = bytes < 0 ? 0 : bytes; }
 
 static const bool g_trace_launch = getenv("ESC_TRACE_LAUNCH") != nullptr && atoi(getenv("ESC_TRACE_LAUNCH")) != 0;

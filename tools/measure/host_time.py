@@ -30,6 +30,11 @@ def step(i):
     opt.step()
     t4 = time.perf_counter()
     return (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+if os.environ.get("ESC_NODE_STREAM"):          # the whole loop on a non-default (non-blocking) stream
+    _side = torch.cuda.Stream()
+    _side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(_side)
+    nxt = store.collate(ids[0])
 for i in range(10): step(i)
 torch.cuda.synchronize()
 # host-only: enqueue 30 steps, time the enqueue; then sync
