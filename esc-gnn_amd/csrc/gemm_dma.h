@@ -781,7 +781,7 @@ template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM,
 inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
   using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
   auto kern = gemm_kernel<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
-  if (BM < 128 && (size_t)node_lds_floor() > lds_floor) lds_floor = (size_t)node_lds_floor();
+  if (BM < 128 && gemm_lds_floor() == 0 && (size_t)node_lds_floor() > lds_floor) lds_floor = (size_t)node_lds_floor();
   const size_t lds = C_::LDS_BYTES > lds_floor ? C_::LDS_BYTES : lds_floor;
   static size_t raised_to = 64 * 1024;      // per instantiation
   hipError_t e = raise_lds(kern, lds, raised_to);
@@ -801,7 +801,7 @@ inline hipError_t launch_dual(DualArgs a, size_t lds_floor, hipStream_t s, int k
   auto kern = gemm_dual_kernel<BM, BN, BK, WM, WN, STAGES, LW, PRO, BNB, BSTAT>;
   const size_t lds_x = CX::LDS_BYTES + (size_t)CX::bnb_lds_floats(a.dx.R) * 4;        // (+ the dX job's per-k BatchNorm coefficients)
   size_t lds = lds_x > CW::LDS_BYTES ? lds_x : CW::LDS_BYTES;
-  if (BM < 128 && (size_t)node_lds_floor() > lds_floor) lds_floor = (size_t)node_lds_floor();
+  if (BM < 128 && gemm_lds_floor() == 0 && (size_t)node_lds_floor() > lds_floor) lds_floor = (size_t)node_lds_floor();
   if (lds_floor > lds) lds = lds_floor;
   static size_t raised_to = 64 * 1024;
   hipError_t e = raise_lds(kern, lds, raised_to);
