@@ -19,3 +19,5 @@ python tools/kernel_roofline.py > gpurun_out/r03/r03_kernel_roofline.txt 2>&1
 python tools/measure/loader_time.py > gpurun_out/r03/r03_dropin_loader_times.txt 2>&1
 python tools/measure/dropin_time.py > gpurun_out/r03/r03_dropin_loop_times.txt 2>&1
 ESC_PHASE_TIMING=1 python tools/measure/host_time.py > gpurun_out/r03/r03_host_and_phase_times.txt 2>&1
+{ python tools/measure/dropin_prof.py flat 2>/dev/null | sed -n 1,1p; python tools/measure/dropin_prof.py adam 2>/dev/null | sed -n 1,1p; } > gpurun_out/r03/r03_dropin_host_times.txt
+for bs in 16 32 64 128; do echo "bs $bs: $(python bench.py --batch_size $bs --steps 60 --warmup 10 --cpu_seconds 0 --no_breakdown 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print(d['value'], 'graphs/s', d['ms_per_step'], 'ms/step')")"; done > gpurun_out/r03/r03_step_time_by_batch_size.txt
