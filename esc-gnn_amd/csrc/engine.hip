@@ -40,6 +40,8 @@ struct Layout {
   float *Zb, *Yz; BnWs zb0, zb1;
   float *A0, *Zemb;               // relu(BN(Zb)) and z_emb = relu(BN(Yz)), materialised when g_materialise_edge_act
   float* e[ESC_MAX_LAYERS]; float* agg[ESC_MAX_LAYERS]; MlpWs conv[ESC_MAX_LAYERS];
+  int64_t ld_e[ESC_MAX_LAYERS];   // leading dimension of e[l]: C, or (L-1)*H when the H-wide edge terms are column blocks of ONE matrix
+  float *e_cat, *w_cat;           // g_edge_batched: [E, (L-1)*H] and the packed [(L-1)*H + (L-1), H] weights ++ biases
   MlpWs xemb; float *cat, *Yl; BnWs bl; float *pred, *dpred;
   // backward scratch
   float *dcat, *dAl, *dT1, *dT2, *dagg, *dZemb, *dAz, *deps_part;
@@ -60,6 +62,10 @@ struct Layout {
   int64_t total;
 };
 
+// SURVEY section 7 step 6, built to be measured: the H-wide edge terms e_1 .. e_{L-1} = lin_l(z_emb) of ALL layers as ONE GEMM
+// [E, H] x [H, (L-1)*H] over packed weights (one launch of 119 x 6 tiles instead of three of 119 x 2), their outputs column blocks of
+// one matrix.  ESC_EDGE_BATCHED=1; see DESIGN.md for what it measured.
+static int g_edge_batched = getenv("ESC_EDGE_BATCHED") ? atoi(getenv("ESC_EDGE_BATCHED")) : 1;
 static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); w.nglob = a.take(16); w.coef = a.take(2 * C); return w; }
 
 static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64_t Z, float* base, bool train) {
@@ -69,9 +75,12 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   y.N = N; y.E = E; y.Z = Z; y.H = H; y.L = L; y.C0 = C0; y.W = (L + 1) * H;
   y.Zb = a.take(E * H); y.Yz = a.take(E * H); y.zb0 = take_bn(a, H); y.zb1 = take_bn(a, H);
   y.A0 = a.take(E * H); y.Zemb = a.take(E * H);
+  const bool batched = g_edge_batched && L >= 3;            // (two or more H-wide edge terms)
+  if (batched) { y.e_cat = a.take(E * (L - 1) * H); y.w_cat = a.take(((L - 1) * H + (L - 1)) * H); }
   for (int l = 0; l < L; ++l) {
     const int64_t C = l == 0 ? C0 : H;
-    y.e[l] = a.take(E * C);
+    if (batched && l >= 1) { y.e[l] = base ? y.e_cat + (int64_t)(l - 1) * H : nullptr; y.ld_e[l] = (L - 1) * H; }
+    else { y.e[l] = a.take(E * C); y.ld_e[l] = C; }
     y.agg[l] = a.take(N * C);
     y.conv[l].Y0 = a.take(N * H); y.conv[l].Y1 = a.take(N * H);
     y.conv[l].b0 = take_bn(a, H); y.conv[l].b1 = take_bn(a, H);
@@ -689,7 +698,24 @@ static int forward(const Ctx& c) {
     return ESC_OK;
   };
   mark(PH_START, c.s);
-  const int ahead = es.ok ? g_edge_ahead : (int)L;          // one stream: all of them up front, in layer order
+  const bool batched = y.e_cat != nullptr && mat;
+  if (batched) {                                            // e_1 .. e_{L-1} in one launch over the packed weights
+    if (!e0_early) ESC_TRY(edge_term(0));
+    esc_table_list tl{};
+    tl.count = 2 * ((int)L - 1);
+    for (int l = 1; l < (int)L; ++l) {
+      tl.rows[l - 1] = (int32_t)H; tl.w[l - 1] = m->conv[l].lin.w;
+      tl.rows[(L - 1) + l - 1] = 1; tl.w[(L - 1) + l - 1] = m->conv[l].lin.b;
+    }
+    ESC_TRY(esc_table_pack(&tl, H, y.w_cat, ce.s));
+    {
+      const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
+      ESC_TRY(esc_linear_fwd(y.Zemb, H, y.w_cat, H, y.w_cat + (L - 1) * H * H, nullptr, nullptr, E, (L - 1) * H, H, y.e_cat, (L - 1) * H, nullptr, ce.s));
+    }
+    for (int l = 1; l < (int)L; ++l)
+      if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+  }
+  const int ahead = batched ? 0 : (es.ok ? g_edge_ahead : (int)L);          // one stream: all of them up front, in layer order
   for (int l = e0_early ? 1 : 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
   // ---- node pipeline (first, while it would otherwise wait for the first edge term: the chunk schedule of the bag
   // gradient, which depends on the batch's index arrays only)
@@ -715,11 +741,11 @@ static int forward(const Ctx& c) {
     const int64_t ld_h = l == 0 ? y.C0 : W;
     if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     if (fuse_node_act(c) && l > 0)          // hin = pre-BatchNorm rows of the previous layer: relu(x*scale+shift) on the fly
-      ESC_TRY(esc_gine_aggregate_fwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], C, b->in_ptr,
+      ESC_TRY(esc_gine_aggregate_fwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], y.ld_e[l], b->in_ptr,
                                             b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
     else
-      ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
-    if (es.ok && l + ahead < (int)L) {
+      ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], y.ld_e[l], b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    if (!batched && es.ok && l + ahead < (int)L) {
       ESC_TRY(chain(es.agg_done[l], (hipStream_t)c.s, es.stream));
       ESC_TRY(edge_term(l + ahead));
     }
@@ -876,15 +902,15 @@ static int backward(const Ctx& c_in, Pending* defer) {
                                                y.dcat + (int64_t)l * H, W, y.dagg, l - 1 == 0 ? y.C0 : H, true);
     if (stats_here) {
       ESC_TRY(esc_gine_aggregate_bwd_affine_stats(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.conv[l - 1].b1.mean,
-                                                  y.conv[l - 1].b1.invstd, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
+                                                  y.conv[l - 1].b1.invstd, y.e[l], y.ld_e[l], y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
                                                   y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * 2 * N, y.bst_part, c.s));
       agg_slots = esc_gine_aggregate_bwd_stats_slots(N);
     } else if (fuse_node_act(c) && l > 0)
-      ESC_TRY(esc_gine_aggregate_bwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], C, y.dagg, C,
+      ESC_TRY(esc_gine_aggregate_bwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], y.ld_e[l], y.dagg, C,
                                             b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C, y.d_e[l], C, dx, W, 1,
                                             y.deps_part + (int64_t)l * 2 * N, c.s));
     else
-      ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
+      ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], y.ld_e[l], y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
                                      y.d_e[l], C, dx, W, 1, y.deps_part + (int64_t)l * 2 * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * 2 * N, N * esc_gine_aggregate_bwd_deps_slots(C), cv.deps});
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));   // lin_l backward: edge stream
@@ -982,9 +1008,13 @@ static Layout plan_layout_zinc(const esc_zinc_gin_t* m, int64_t N, int64_t E, in
   y.X0 = a.take(N * C0);
   y.Zb = a.take(E * H); y.Yz = a.take(E * H); y.zb0 = take_bn(a, H); y.zb1 = take_bn(a, H);
   y.A0 = a.take(E * H); y.Zcat = a.take(E * y.Wz);
+  const int64_t lb = C0 == H ? 0 : 1, nb = L - lb;            // the H-wide edge terms: layers lb .. L-1, batched into one GEMM (g_edge_batched)
+  const bool batched = g_edge_batched && nb >= 2;
+  if (batched) { y.e_cat = a.take(E * nb * H); y.w_cat = a.take(nb * H * y.Wz + nb * H); }
   for (int l = 0; l < L; ++l) {
     const int64_t C = l == 0 ? C0 : H;
-    y.e[l] = a.take(E * C);
+    if (batched && l >= lb) { y.e[l] = base ? y.e_cat + (int64_t)(l - lb) * H : nullptr; y.ld_e[l] = nb * H; }
+    else { y.e[l] = a.take(E * C); y.ld_e[l] = C; }
     y.agg[l] = a.take(N * C);
     y.conv[l].Y0 = a.take(N * H); y.conv[l].Y1 = a.take(N * H); y.conv[l].A1 = a.take(N * H);
     y.conv[l].b0 = take_bn(a, H); y.conv[l].b1 = take_bn(a, H);
@@ -1054,7 +1084,27 @@ static int forward_zinc(const ZincCtx& z) {
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_zinc: stream event failed"); return ESC_ELAUNCH; }
     return ESC_OK;
   };
-  const int ahead = es.ok ? g_edge_ahead : (int)L;
+  const bool batched = y.e_cat != nullptr;
+  if (batched) {                      // every H-wide edge term in one launch over the packed weights (rows of Wz floats) ++ biases
+    const int lb = C0 == H ? 0 : 1, nb = (int)L - lb;
+    if (lb == 1) ESC_TRY(edge_term(0));
+    // (two packs: the weight rows are Wz wide, the biases H wide)
+    esc_table_list tw{}, tb{};
+    tw.count = nb; tb.count = nb;
+    for (int l = lb; l < (int)L; ++l) {
+      tw.rows[l - lb] = (int32_t)H; tw.w[l - lb] = m->conv[l].lin.w;
+      tb.rows[l - lb] = 1; tb.w[l - lb] = m->conv[l].lin.b;
+    }
+    ESC_TRY(esc_table_pack(&tw, Wz, y.w_cat, ce.s));
+    ESC_TRY(esc_table_pack(&tb, H, y.w_cat + (int64_t)nb * H * Wz, ce.s));
+    {
+      const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
+      ESC_TRY(esc_linear_fwd(y.Zcat, Wz, y.w_cat, Wz, y.w_cat + (int64_t)nb * H * Wz, nullptr, nullptr, E, nb * H, Wz, y.e_cat, nb * H, nullptr, ce.s));
+    }
+    for (int l = lb; l < (int)L; ++l)
+      if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_zinc: stream event failed"); return ESC_ELAUNCH; }
+  }
+  const int ahead = batched ? 0 : (es.ok ? g_edge_ahead : (int)L);
   for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
   // ---- node pipeline: x = node_type_embedding(data.x) (:581)
   ESC_TRY(esc_embed_fwd(m->node_emb.w, m->node_emb.rows, C0, b->node_type, N, y.X0, C0, nullptr, c.s));
@@ -1065,8 +1115,8 @@ static int forward_zinc(const ZincCtx& z) {
     const float* hin = l == 0 ? y.X0 : y.cat + (int64_t)(l - 1) * H;
     const int64_t ld_h = l == 0 ? C0 : W;
     if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_zinc: stream event failed"); return ESC_ELAUNCH; }
-    ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], C, b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
-    if (es.ok && l + ahead < (int)L) {
+    ESC_TRY(esc_gine_aggregate_fwd(hin, ld_h, y.e[l], y.ld_e[l], b->in_ptr, b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
+    if (!batched && es.ok && l + ahead < (int)L) {
       ESC_TRY(chain(es.agg_done[l], (hipStream_t)c.s, es.stream));
       ESC_TRY(edge_term(l + ahead));
     }
@@ -1105,7 +1155,7 @@ static int backward_zinc(const ZincCtx& z) {
     const int64_t ld_h = l == 0 ? C0 : W;
     ESC_TRY(mlp_backward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)l * H, W, y.dcat + (int64_t)l * H, W, y.dagg, C));
     float* dx = l == 0 ? y.dX0 : y.dcat + (int64_t)(l - 1) * H;
-    ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], C, y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
+    ESC_TRY(esc_gine_aggregate_bwd(hin, ld_h, y.e[l], y.ld_e[l], y.dagg, C, b->out_ptr, b->out_edge, b->out_dst, cv.eps, N, C,
                                    y.d_e[l], C, dx, l == 0 ? C0 : W, l == 0 ? 0 : 1, y.deps_part + (int64_t)l * 2 * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * 2 * N, N * esc_gine_aggregate_bwd_deps_slots(C), cv.deps});
     if (es.ok) ESC_TRY(chain(es.de_ready[l], (hipStream_t)c.s, es.stream));      // conv.lin backward: edge stream
