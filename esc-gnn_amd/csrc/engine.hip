@@ -1236,6 +1236,7 @@ struct OgbLayout {
   float *Zb, *Zd, *A0, *Yz, *Yzd, *Zemb; BnWs zb0, zb1;
   unsigned char *mask_z0, *mask_z1;
   OgbLayer l[ESC_MAX_LAYERS];
+  float *e_cat, *w_cat; int64_t ld_e;     // g_edge_batched: every layer's edge term is a column block of ONE [E, L*H] matrix
   float *h[ESC_MAX_LAYERS + 1];
   float *pooled, *logits, *dlogits;
   // backward
@@ -1261,10 +1262,16 @@ static OgbLayout plan_layout_ogb(const esc_ogb_gnn_t* m, int64_t N, int64_t E, i
   y.Yz = a.take(E * H); y.Yzd = drop ? a.take(E * H) : y.Yz; y.Zemb = a.take(E * H);
   y.zb0 = take_bn(a, H); y.zb1 = take_bn(a, H);
   if (drop) { y.mask_z0 = take_bytes(a, E * H); y.mask_z1 = take_bytes(a, E * H); }
+  // see plan_layout(): the edge terms of layers 1 .. L-1 from one GEMM (layer 0's keeps its own launch: the first aggregate waits for it)
+  const bool batched = g_edge_batched >= 2 && L >= 3 && H % 4 == 0;
+  y.ld_e = batched ? (L - 1) * H : H;
+  if (batched) { y.e_cat = a.take(E * (L - 1) * H); y.w_cat = a.take((L - 1) * H * H + (L - 1) * H); }
   for (int l = 0; l < L; ++l) {
     OgbLayer& q = y.l[l];
     q.vn = a.take(G * H);
-    q.hin = a.take(N * H); q.e = a.take(E * H); q.agg = a.take(N * H);
+    q.hin = a.take(N * H);
+    q.e = (batched && l >= 1) ? y.e_cat + (int64_t)(l - 1) * H : a.take(E * H);
+    q.agg = a.take(N * H);
     q.Y0 = a.take(N * H2); q.A1 = a.take(N * H2); q.hc = a.take(N * H); q.hb = nullptr;         // (hb is never materialised: BN -> ReLU -> dropout in one pass)
     q.b0 = take_bn(a, H2); q.bn = take_bn(a, H);
     y.h[l + 1] = a.take(N * H);
@@ -1357,7 +1364,27 @@ static int forward_ogb(const OgbCtx& z) {
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_ogb: stream event failed"); return ESC_ELAUNCH; }
     return ESC_OK;
   };
-  const int ahead = es.ok ? g_edge_ahead : (int)L;
+  const bool batched = y.ld_e != H;
+  if (batched) {                        // layer 0's edge term first, then edge_encoder_pos of layers 1 .. L-1 in one launch + their bond sums
+    ESC_TRY(edge_term(0));
+    const int nb = (int)L - 1;
+    esc_table_list tl{};
+    tl.count = 2 * nb;
+    for (int l = 1; l < (int)L; ++l) {
+      tl.rows[l - 1] = (int32_t)H; tl.w[l - 1] = m->layer[l].pos.w;
+      tl.rows[nb + l - 1] = 1; tl.w[nb + l - 1] = m->layer[l].pos.b;
+    }
+    ESC_TRY(esc_table_pack(&tl, H, y.w_cat, ce.s));
+    {
+      const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
+      ESC_TRY(esc_linear_fwd(y.Zemb, H, y.w_cat, H, y.w_cat + (int64_t)nb * H * H, nullptr, nullptr, E, nb * H, H, y.e_cat, nb * H, nullptr, ce.s));
+    }
+    for (int l = 1; l < (int)L; ++l) {
+      ESC_TRY(esc_bag_fwd_rows(y.Tcat + m->layer[l].bond_row0 * H, m->bond_rows, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, y.l[l].e, y.ld_e, 1, nullptr, ce.s));
+      if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_ogb: stream event failed"); return ESC_ELAUNCH; }
+    }
+  }
+  const int ahead = batched ? 0 : (es.ok ? g_edge_ahead : (int)L);
   for (int l = 0; l < (int)L && l < ahead; ++l) ESC_TRY(edge_term(l));
   // ---- node pipeline: h0 = AtomEncoder(x) (:264-282); vn_0 = virtualnode_embedding(0) per graph (:701)
   ESC_TRY(esc_bag_fwd_rows(y.Tcat, m->atom_rows, H, b->atoms.row_ptr, b->atoms.idx, b->atoms.ones, N, y.h0, H, 0, nullptr, c.s));
@@ -1367,8 +1394,8 @@ static int forward_ogb(const OgbCtx& z) {
     const OgbLayer& w = y.l[l];
     ESC_TRY(esc_segment_broadcast_add(y.h[l], H, w.vn, H, b->graph_ptr, G, N, H, w.hin, H, c.s));                 // :739
     if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_ogb: stream event failed"); return ESC_ELAUNCH; }
-    ESC_TRY(esc_gine_aggregate_fwd(w.hin, H, w.e, H, b->in_ptr, b->in_edge, b->in_src, q.eps, N, H, w.agg, H, c.s));
-    if (es.ok && l + ahead < (int)L) {
+    ESC_TRY(esc_gine_aggregate_fwd(w.hin, H, w.e, l == 0 ? H : y.ld_e, b->in_ptr, b->in_edge, b->in_src, q.eps, N, H, w.agg, H, c.s));
+    if (!batched && es.ok && l + ahead < (int)L) {
       ESC_TRY(chain(es.agg_done[l], (hipStream_t)c.s, es.stream));
       ESC_TRY(edge_term(l + ahead));
     }
@@ -1471,7 +1498,7 @@ static int backward_ogb(const OgbCtx& z) {
       float* t = dH; dH = dHin; dHin = t;          // d hin starts as d h_{l+1}: accumulate into that buffer
       have_dhin = true;
     }
-    ESC_TRY(esc_gine_aggregate_bwd(w.hin, H, w.e, H, y.dagg, H, b->out_ptr, b->out_edge, b->out_dst, q.eps, N, H, w.d_e, H,
+    ESC_TRY(esc_gine_aggregate_bwd(w.hin, H, w.e, l == 0 ? H : y.ld_e, y.dagg, H, b->out_ptr, b->out_edge, b->out_dst, q.eps, N, H, w.d_e, H,
                                    dHin, H, have_dhin ? 1 : 0, y.deps_part + (int64_t)l * 2 * N, c.s));
     eps_jobs.push_back(esc_sum_job{y.deps_part + (int64_t)l * 2 * N, N * esc_gine_aggregate_bwd_deps_slots(H), q.deps});
     // edge term: bond tables and edge_encoder_pos — edge stream
