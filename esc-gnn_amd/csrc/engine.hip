@@ -680,7 +680,7 @@ static int forward(const Ctx& c) {
   const bool e0_early = mat && g_e0_early && y.C0 <= 32 && L >= 1;
   if (e0_early) {
     const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
-    ESC_TRY(esc_linear_fwd(y.Yz, H, m->conv[0].lin.w, H, m->conv[0].lin.b, y.zb1.scale, y.zb1.shift, E, y.C0, H, y.e[0], y.C0, nullptr, ce.s));
+    ESC_TRY(esc_linear_fwd(y.Yz, H, m->conv[0].lin.w, H, m->conv[0].lin.b, y.zb1.scale, y.zb1.shift, E, y.C0, H, y.e[0], y.ld_e[0], nullptr, ce.s));
     if (es.ok && hipEventRecord(es.e_ready[0], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
   }
   if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, ce.s));
@@ -692,8 +692,8 @@ static int forward(const Ctx& c) {
     const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
     const esc_conv_t& cv = m->conv[l];
     const int64_t C = l == 0 ? y.C0 : H;
-    if (mat) ESC_TRY(esc_linear_fwd(y.Zemb, H, cv.lin.w, H, cv.lin.b, nullptr, nullptr, E, C, H, y.e[l], C, nullptr, ce.s));
-    else     ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], C, nullptr, ce.s));
+    if (mat) ESC_TRY(esc_linear_fwd(y.Zemb, H, cv.lin.w, H, cv.lin.b, nullptr, nullptr, E, C, H, y.e[l], y.ld_e[l], nullptr, ce.s));
+    else     ESC_TRY(esc_linear_fwd(y.Yz, H, cv.lin.w, H, cv.lin.b, y.zb1.scale, y.zb1.shift, E, C, H, y.e[l], y.ld_e[l], nullptr, ce.s));
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     return ESC_OK;
   };
@@ -1080,7 +1080,7 @@ static int forward_zinc(const ZincCtx& z) {
     const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
     const esc_conv_t& cv = m->conv[l];
     const int64_t C = l == 0 ? C0 : H;
-    ESC_TRY(esc_linear_fwd(y.Zcat, Wz, cv.lin.w, Wz, cv.lin.b, nullptr, nullptr, E, C, Wz, y.e[l], C, nullptr, ce.s));
+    ESC_TRY(esc_linear_fwd(y.Zcat, Wz, cv.lin.w, Wz, cv.lin.b, nullptr, nullptr, E, C, Wz, y.e[l], y.ld_e[l], nullptr, ce.s));
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_zinc: stream event failed"); return ESC_ELAUNCH; }
     return ESC_OK;
   };
@@ -1359,8 +1359,9 @@ static int forward_ogb(const OgbCtx& z) {
   auto edge_term = [&](int l) -> int {
     const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
     const esc_ogb_layer_t& q = m->layer[l];
-    ESC_TRY(esc_linear_fwd(y.Zemb, H, q.pos.w, H, q.pos.b, nullptr, nullptr, E, H, H, y.l[l].e, H, nullptr, ce.s));
-    ESC_TRY(esc_bag_fwd_rows(y.Tcat + q.bond_row0 * H, m->bond_rows, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, y.l[l].e, H, 1, nullptr, ce.s));
+    const int64_t ld = (l == 0 || y.ld_e == H) ? H : y.ld_e;
+    ESC_TRY(esc_linear_fwd(y.Zemb, H, q.pos.w, H, q.pos.b, nullptr, nullptr, E, H, H, y.l[l].e, ld, nullptr, ce.s));
+    ESC_TRY(esc_bag_fwd_rows(y.Tcat + q.bond_row0 * H, m->bond_rows, H, b->bonds.row_ptr, b->bonds.idx, b->bonds.ones, E, y.l[l].e, ld, 1, nullptr, ce.s));
     if (es.ok && hipEventRecord(es.e_ready[l], es.stream) != hipSuccess) { set_error("esc_ogb: stream event failed"); return ESC_ELAUNCH; }
     return ESC_OK;
   };
