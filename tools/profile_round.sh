@@ -46,7 +46,7 @@ t = float(agg["AverageNs"]) * 1e-3
 print("  traced run, rocprofv3 kernel stats        : %d calls, average %.2f us -> %.0f GB/s = %.3f of 8 TB/s" % (int(agg["Calls"]), t, alg / t / 1e3, alg / t / 1e3 / 8000))
 print("  traced run, bench.py event pairs          : %d launches, average %.2f us -> frac %.3f (under the tracer the start marker queues behind the profiler's packets)" % (rf["launches"], rf["avg_us"], rf["frac"]))
 p = plain["roofline"]
-print("  untraced run (%s), pairs  : %d launches, average %.2f us -> frac %.3f (median %.2f us, fastest %.2f us)  <- the reported figure (conservative): %.0f %% above the rocprofv3 average - the pair spans start marker -> kernel end, i.e. the dispatch latency behind the kernel in front is inside it (DESIGN.md 5)" % (sys.argv[3].split("/")[-1], p["launches"], p["avg_us"], p["frac"], p["median_us"], p["min_us"], abs(p["avg_us"] - t) / t * 100))
+print("  untraced run (%s), pairs  : %d launches, average %.2f us -> frac %.3f (median %.2f us, fastest %.2f us)  <- the reported figure (conservative): %.0f %% above the rocprofv3 average of the TRACED step, which is host-bound: there the kernel starts after an idle gap, here right behind the kernel in front (DESIGN.md 5)" % (sys.argv[3].split("/")[-1], p["launches"], p["avg_us"], p["frac"], p["median_us"], p["min_us"], abs(p["avg_us"] - t) / t * 100))
 gemm = [(n, r) for n, r in rows.items() if "gemm_kernel" in n or "gemm_dual_kernel" in n or "gemm_tile_kernel" in n or "linear_narrow" in n or "small::" in n]
 tot = sum(float(r["TotalDurationNs"]) for _, r in gemm)
 dual = next((r for n, r in rows.items() if "gemm_dual_kernel<128, 128" in n), None)
