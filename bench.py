@@ -312,6 +312,8 @@ def main():
     alg_bytes = aggregate_bytes(N_avg, E_avg, args.hidden)
     avg_ms = ms_agg / max(n_agg, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if n_agg else 0.0
+    per_step = max(args.layers - 1, 1)                      # launch i of a step belongs to layer 1 + i % (L-1)
+    by_layer = [round(1e3 * sum(agg_launch_ms[k::per_step]) / max(len(agg_launch_ms[k::per_step]), 1), 2) for k in range(per_step)] if agg_launch_ms else []
     per_launch = sorted(agg_launch_ms)
     med_ms = per_launch[len(per_launch) // 2] if per_launch else 0.0
     min_ms = per_launch[0] if per_launch else 0.0
@@ -327,18 +329,36 @@ def main():
         traffic = tj.get("traffic_bytes_per_launch")
         tsrc = ("committed PMC passes of this command (profiles/%s: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
                 "runs, FETCH x2 gfx950 correction, tools/parse_pmc.py) - NOT measured in this run" % os.path.basename(tpaths[-1]))
+    # the same kernel's average in the committed rocprofv3 kernel trace of this command (a TRACED, host-bound step: quoted for
+    # reconciliation with `avg_us`, never used in `frac`)
+    rp_avg, rp_src = None, None
+    spaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
+    if spaths:
+        try:
+            import csv
+            for row in csv.DictReader(open(spaths[-1])):
+                if "agg_fwd_wave<2" in row.get("Name", "") or ("agg_fwd_wave<4, true" in row.get("Name", "") and rp_avg is None):
+                    rp_avg = round(float(row["AverageNs"]) * 1e-3, 2)
+                    rp_src = "profiles/%s (rocprofv3 --kernel-trace --stats of this command; not measured in this run)" % os.path.basename(spaths[-1])
+                    if "agg_fwd_wave<2" in row["Name"]:
+                        break
+        except Exception:
+            rp_avg, rp_src = None, None
     split = "2, true> (two waves per destination row" if (args.hidden == 256 and os.environ.get("ESC_AGG_SPLIT", "2") == "2") else "4, true> (one wave per destination row"
     roofline = dict(kernel="esc::agg_fwd_wave<%s; GINE aggregate forward = the scatter-add, C=%d; the gathered rows get the previous "
                            "layer's BatchNorm+ReLU applied as they are read)" % (split, args.hidden),
                     bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None if traffic is None else int(traffic),
+                    frac=round(achieved / HBM_PEAK_GBS, 4), by_layer_us=by_layer, rocprofv3_avg_us=rp_avg, rocprofv3_source=rp_src,
+                    frac_rocprofv3=None if not rp_avg else round(alg_bytes / (rp_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=None if traffic is None else int(traffic),
                     traffic_source=tsrc,
                     hbm_frac=None if (traffic is None or not n_agg) else round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     launches=n_agg, avg_us=round(avg_ms * 1e3, 2), median_us=round(med_ms * 1e3, 2), min_us=round(min_ms * 1e3, 2),
                     frac_median=round(alg_bytes / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if med_ms > 0 else None,
                     frac_min_time=round(alg_bytes / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if min_ms > 0 else None,
                     clock="hipExtLaunchKernelGGL start/stop event pair per launch on the launch stream, inside the timed region; "
-                          "mean over all launches (frac), median and fastest launch alongside",
+                          "mean over all launches (frac), median and fastest launch alongside.  The start event is a marker that "
+                          "completes when the kernel in front has drained, so a pair = inter-kernel dispatch gap + kernel: the kernel's own "
+                          "begin -> end (what rocprofv3 reports) is rocprofv3_avg_us",
                     alg_bytes_per_launch=int(alg_bytes))
     extra = {}
     if "linear" in breakdown and breakdown["linear"]["ms_per_step"] > 0:

@@ -65,6 +65,7 @@ struct Layout {
 // SURVEY section 7 step 6, built to be measured: the H-wide edge terms e_1 .. e_{L-1} = lin_l(z_emb) of ALL layers as ONE GEMM
 // [E, H] x [H, (L-1)*H] over packed weights (one launch of 119 x 6 tiles instead of three of 119 x 2), their outputs column blocks of
 // one matrix.  ESC_EDGE_BATCHED=1; see DESIGN.md for what it measured.
+static int g_skip_waits = getenv("ESC_SKIP_WAITS") ? atoi(getenv("ESC_SKIP_WAITS")) : 1;
 static int g_edge_batched = getenv("ESC_EDGE_BATCHED") ? atoi(getenv("ESC_EDGE_BATCHED")) : 1;
 static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); w.nglob = a.take(16); w.coef = a.take(2 * C); return w; }
 
@@ -739,7 +740,8 @@ static int forward(const Ctx& c) {
     const int64_t C = l == 0 ? y.C0 : H;
     const float* hin = l == 0 ? b->x : y.cat + (int64_t)l * H;
     const int64_t ld_h = l == 0 ? y.C0 : W;
-    if (es.ok && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+    // (batched edge terms: e_1 .. e_{L-1} come out of one launch, the wait in front of layer 1 covers the later layers)
+    if (es.ok && !(batched && l >= 2 && g_skip_waits) && hipStreamWaitEvent((hipStream_t)c.s, es.e_ready[l], 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
     if (fuse_node_act(c) && l > 0)          // hin = pre-BatchNorm rows of the previous layer: relu(x*scale+shift) on the fly
       ESC_TRY(esc_gine_aggregate_fwd_affine(hin, ld_h, y.cat_scale + (int64_t)l * H, y.cat_shift + (int64_t)l * H, y.e[l], y.ld_e[l], b->in_ptr,
                                             b->in_edge, b->in_src, cv.eps, N, C, y.agg[l], C, c.s));
