@@ -59,6 +59,8 @@ SIGNATURES = {
     "esc_prof_read": [I32, POINTER(c_int64), POINTER(c_double)],
     "esc_prof_reset": [I32],
     "esc_prof_read_all": [I32, POINTER(c_double), c_int64],
+    "esc_prof_span_arm": [I32, c_int64, P],
+    "esc_prof_span_read": [I32, POINTER(c_double), c_int64],
     "esc_bag_fwd": [P, I64, P, P, P, I64, P, I64, P],
     "esc_bag_fwd_rows": [P, I64, I64, P, P, P, I64, P, I64, I32, P, P],
     "esc_bag_fwd_stats_block_rows": [P, I64, I64, P, I64, I64],
@@ -159,7 +161,7 @@ SIGNATURES = {
     "esc_features_count": [P, P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, P, P, P],
     "esc_features_fill": [P, P, I64, I64, I64, I64, I64, I32, I32, I32, P, P, I64, P, P, P, P, P, P, P, P, P],
 }
-_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_bag_fwd_stats_block_rows": c_int64, "esc_gine_aggregate_bwd_stats_slots": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_embed_plan_scratch": c_int64, "esc_prof_read_all": c_int64,
+_RET = {"esc_last_error": ctypes.c_char_p, "esc_bag_bwd_scratch": c_int64, "esc_bag_fwd_stats_block_rows": c_int64, "esc_gine_aggregate_bwd_stats_slots": c_int64, "esc_linear_stats_block_rows": c_int64, "esc_plan_csr_scratch": c_int64, "esc_embed_plan_scratch": c_int64, "esc_prof_read_all": c_int64, "esc_prof_span_read": c_int64,
         "esc_linear_bwd_weight_scratch": c_int64, "esc_bn_scratch": c_int64, "esc_linear_bwd_bn_block_rows": c_int64,
         "esc_features_scratch_bytes": c_int64, "esc_engine_workspace_floats": c_int64,
         "esc_zinc_workspace_floats": c_int64, "esc_ogb_workspace_floats": c_int64}
@@ -230,6 +232,18 @@ def prof_read(kind):
     n, ms = c_int64(0), c_double(0.0)
     call("esc_prof_read", KIND[kind], ctypes.byref(n), ctypes.byref(ms))
     return n.value, ms.value
+
+
+def prof_span_arm(kind, launches):
+    """also stamp the in-kernel execution window of the next `launches` profiled launches (kernels with a span argument)"""
+    call("esc_prof_span_arm", KIND[kind], int(launches), stream())
+
+
+def prof_span_read(kind, cap=1 << 16):
+    """execution windows (us) of the armed launches, in launch order — call after a device synchronise"""
+    buf = (c_double * cap)()
+    n = lib().esc_prof_span_read(KIND[kind], buf, cap)
+    return [buf[i] for i in range(n)]
 
 
 def prof_read_all(kind, cap=1 << 16):

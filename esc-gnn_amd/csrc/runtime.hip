@@ -1,5 +1,6 @@
 // runtime.hip — error reporting + HIP-event kernel-family profiler of libescgnn_hip.so
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 #include <mutex>
@@ -39,6 +40,21 @@ bool prof_slot(int k, hipEvent_t* start, hipEvent_t* stop) {
   *stop = p.stop[p.used];
   ++p.used;
   return true;
+}
+
+// in-kernel execution windows of a profiled kernel family (esc_prof_span_*): per launch ESC_SPAN_WGS start slots (one per workgroup)
+// and ESC_SPAN_WAVES end slots (one per wave), written by kernels that take a `span` argument
+struct SpanState { unsigned long long* dev = nullptr; size_t cap = 0; };
+static SpanState g_span[ESC_K_COUNT];
+unsigned long long* prof_span_next(int k) {
+  if (k < 0 || k >= ESC_K_COUNT) return nullptr;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof[k].on || g_span[k].dev == nullptr || g_prof[k].used >= g_span[k].cap) return nullptr;
+  return g_span[k].dev + g_prof[k].used * ESC_SPAN_STRIDE;
+}
+__global__ void span_init_kernel(unsigned long long* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (i % ESC_SPAN_STRIDE) < ESC_SPAN_WGS ? ~0ULL : 0ULL;
 }
 
 // ticket counters for grid_last_block (common.h): one zeroed pool per device, handed out as rotating windows
@@ -127,6 +143,43 @@ int esc_prof_read(int kind, int64_t* launches, double* total_ms) {
   *launches = (int64_t)p.used;
   *total_ms = tot;
   return ESC_OK;
+}
+
+int esc_prof_span_arm(int kind, int64_t launches, void* stream) {
+  ESC_REQUIRE(kind >= 0 && kind < ESC_K_COUNT && launches > 0 && launches <= 4096, "esc_prof_span_arm: 1..4096 launches");
+  std::lock_guard<std::mutex> lk(esc::g_prof_mu);
+  esc::SpanState& sp = esc::g_span[kind];
+  if (sp.cap < (size_t)launches) {
+    if (sp.dev) (void)hipFree(sp.dev);
+    sp.dev = nullptr; sp.cap = 0;
+    if (hipMalloc(&sp.dev, (size_t)launches * ESC_SPAN_STRIDE * sizeof(unsigned long long)) != hipSuccess) { esc::set_error("esc_prof_span_arm: allocation failed"); return ESC_ELAUNCH; }
+    sp.cap = (size_t)launches;
+  }
+  const size_t n = sp.cap * ESC_SPAN_STRIDE;
+  hipLaunchKernelGGL(esc::span_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sp.dev, n);
+  return ESC_OK;
+}
+
+/* execution windows (us) of the first launches of `kind` recorded since esc_prof_reset; the caller has synchronised */
+int64_t esc_prof_span_read(int kind, double* us_out, int64_t cap) {
+  if (kind < 0 || kind >= ESC_K_COUNT || us_out == nullptr || cap <= 0) return 0;
+  std::lock_guard<std::mutex> lk(esc::g_prof_mu);
+  esc::SpanState& sp = esc::g_span[kind];
+  const size_t n = std::min<size_t>(std::min<size_t>(esc::g_prof[kind].used, sp.cap), (size_t)cap);
+  if (n == 0 || sp.dev == nullptr) return 0;
+  std::vector<unsigned long long> h(n * ESC_SPAN_STRIDE);
+  if (hipMemcpy(h.data(), sp.dev, n * ESC_SPAN_STRIDE * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  int dev = 0, khz = 100000;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+  for (size_t i = 0; i < n; ++i) {
+    unsigned long long lo = ~0ULL, hi = 0ULL;
+    const unsigned long long* q = h.data() + i * ESC_SPAN_STRIDE;
+    for (int w = 0; w < ESC_SPAN_WGS; ++w) lo = std::min(lo, q[w]);
+    for (int w = 0; w < ESC_SPAN_WAVES; ++w) hi = std::max(hi, q[ESC_SPAN_WGS + w]);
+    us_out[i] = (hi > lo && lo != ~0ULL) ? (double)(hi - lo) * 1e3 / (double)khz : 0.0;
+  }
+  return (int64_t)n;
 }
 
 /* per-launch durations (ms) of the recorded launches of `kind`, in launch order; returns how many were written */

@@ -41,6 +41,13 @@ int esc_prof_read(int kind, int64_t* launches, double* total_ms);
 /* per-launch durations (ms) in launch order; returns the number written (<= cap) */
 int64_t esc_prof_read_all(int kind, double* ms_out, int64_t cap);  /* host; syncs recorded events */
 int esc_prof_reset(int kind);
+/* In-kernel execution windows, for kernels that take a `span` argument (the scatter-add, esc_gine_aggregate_fwd_affine): after
+ * esc_prof_span_arm(kind, n, stream) the first n profiled launches of `kind` also stamp the device's wall clock — the earliest first
+ * instruction of a workgroup, the latest last instruction of a wave — into per-launch slots (plain stores, n <= 4096); esc_prof_span_read
+ * returns max - min per launch in microseconds (after the caller has synchronised).  An event pair (above) = inter-kernel dispatch gap + kernel; rocprofv3 =
+ * the dispatch packet's begin -> end; this = first wave in -> last wave out.  Re-arm after esc_prof_reset. */
+int esc_prof_span_arm(int kind, int64_t launches, void* stream);
+int64_t esc_prof_span_read(int kind, double* us_out, int64_t cap);
 
 /* ---- a-6 ESC bag: z[k,:] = sum_j val_j * W[idx_j,:]  (run_graphcount.py:155) -------------
  * forward order = entry order inside the row with separate mul/add roundings, i.e. bitwise what

@@ -44,9 +44,14 @@ rf = line["roofline"]; alg = rf["alg_bytes_per_launch"]
 print("kernel esc::agg_fwd_wave<2, true> (the wide scatter-add launches of the step, two waves per destination row), algorithmic bytes per launch %d:" % alg)
 t = float(agg["AverageNs"]) * 1e-3
 print("  traced run, rocprofv3 kernel stats        : %d calls, average %.2f us -> %.0f GB/s = %.3f of 8 TB/s" % (int(agg["Calls"]), t, alg / t / 1e3, alg / t / 1e3 / 8000))
-print("  traced run, bench.py event pairs          : %d launches, average %.2f us -> frac %.3f (under the tracer the start marker queues behind the profiler's packets)" % (rf["launches"], rf["avg_us"], rf["frac"]))
+ep = rf.get("event_pairs", rf)
+print("  traced run, in-kernel window (bench.py)   : %d launches, average %.2f us -> frac %.3f  <- the live clock and rocprofv3 in the SAME run: %.0f %% apart (the window excludes the launch ramp)" % (rf["launches"], rf["avg_us"], rf["frac"], abs(rf["avg_us"] - t) / t * 100))
+print("  traced run, bench.py event pairs          : %d launches, average %.2f us -> frac %.3f (under the tracer the start marker queues behind the profiler's packets)" % (ep["launches"], ep["avg_us"], ep["frac"]))
 p = plain["roofline"]
-print("  untraced run (%s), pairs  : %d launches, average %.2f us -> frac %.3f (median %.2f us, fastest %.2f us)  <- the reported figure (conservative): %.0f %% above the rocprofv3 average of the TRACED step, which is host-bound: there the kernel starts after an idle gap, here right behind the kernel in front (DESIGN.md 5)" % (sys.argv[3].split("/")[-1], p["launches"], p["avg_us"], p["frac"], p["median_us"], p["min_us"], abs(p["avg_us"] - t) / t * 100))
+print("  untraced run (%s), in-kernel window: %d launches, average %.2f us -> frac %.3f (median %.2f us, fastest %.2f us)  <- the reported figure: first workgroup in -> last wave out on the device wall clock (the same clock under the tracer: %.2f us)" % (sys.argv[3].split("/")[-1], p["launches"], p["avg_us"], p["frac"], p["median_us"], p["min_us"], rf["avg_us"]))
+pp = p.get("event_pairs")
+if pp:
+    print("  untraced run, event pairs                 : %d launches, average %.2f us -> frac %.3f (by layer %s): inter-kernel dispatch gap + kernel" % (pp["launches"], pp["avg_us"], pp["frac"], pp["by_layer_us"]))
 gemm = [(n, r) for n, r in rows.items() if "gemm_kernel" in n or "gemm_dual_kernel" in n or "gemm_tile_kernel" in n or "linear_narrow" in n or "small::" in n]
 tot = sum(float(r["TotalDurationNs"]) for _, r in gemm)
 dual = next((r for n, r in rows.items() if "gemm_dual_kernel<128, 128" in n), None)
