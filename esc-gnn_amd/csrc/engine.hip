@@ -43,6 +43,7 @@ struct Layout {
   int64_t ld_e[ESC_MAX_LAYERS];   // leading dimension of e[l]: C, or (L-1)*H when the H-wide edge terms are column blocks of ONE matrix
   float *e_cat, *w_cat;           // g_edge_batched: [E, (L-1)*H] and the packed [(L-1)*H + (L-1), H] weights ++ biases
   MlpWs xemb; float *cat, *Yl; BnWs bl; float *pred, *dpred;
+  float *Ypart;                   // readout: lin1 over the concat slices that are final before the last layer (g_readout_split)
   // backward scratch
   float *dcat, *dAl, *dT1, *dT2, *dagg, *dZemb, *dAz, *deps_part;
   float *dT1_l[ESC_MAX_LAYERS], *dT2_l[ESC_MAX_LAYERS];   // per-layer copies: read by weight-gradient tiles that run behind the node chain (g_wgrad_stream)
@@ -65,6 +66,10 @@ struct Layout {
 // SURVEY section 7 step 6, built to be measured: the H-wide edge terms e_1 .. e_{L-1} = lin_l(z_emb) of ALL layers as ONE GEMM
 // [E, H] x [H, (L-1)*H] over packed weights (one launch of 119 x 6 tiles instead of three of 119 x 2), their outputs column blocks of
 // one matrix.  ESC_EDGE_BATCHED=1; see DESIGN.md for what it measured.
+// The readout Linear reduces over all (L+1)*H concat columns (K = 1280: 152 workgroups walking 40 K-steps, 33 us — the longest kernel of
+// the node forward).  L of its L+1 slices are final before the LAST layer starts: their share is computed on the idle edge stream while
+// that layer runs, and the launch on the node chain starts from it and only reduces over the last slice (esc_linear_fwd_from).
+static int g_readout_split = getenv("ESC_READOUT_SPLIT") ? atoi(getenv("ESC_READOUT_SPLIT")) : 0;    // measured neutral (1.012-1.016 ms either way): off
 static int g_skip_waits = getenv("ESC_SKIP_WAITS") ? atoi(getenv("ESC_SKIP_WAITS")) : 1;   // -7 us of step time
 static int g_edge_batched = getenv("ESC_EDGE_BATCHED") ? atoi(getenv("ESC_EDGE_BATCHED")) : 1;
 static BnWs take_bn(Arena& a, int64_t C) { BnWs w; w.mean = a.take(C); w.invstd = a.take(C); w.scale = a.take(C); w.shift = a.take(C); w.nglob = a.take(16); w.coef = a.take(2 * C); return w; }
@@ -88,6 +93,7 @@ static Layout plan_layout(const esc_nested_gin_t* m, int64_t N, int64_t E, int64
   }
   y.xemb.Y0 = a.take(N * H); y.xemb.Y1 = a.take(N * H); y.xemb.b0 = take_bn(a, H); y.xemb.b1 = take_bn(a, H);
   y.cat = a.take(N * y.W); y.Yl = a.take(N * H); y.bl = take_bn(a, H);
+  y.Ypart = a.take(N * H);
   y.cat_scale = a.take(y.W); y.cat_shift = a.take(y.W);       // the slices' BatchNorm coefficients side by side (readout prologue)
   if (base) {
     y.xemb.b1.scale = y.cat_scale; y.xemb.b1.shift = y.cat_shift;
@@ -734,6 +740,10 @@ static int forward(const Ctx& c) {
   } else {
     ESC_TRY(mlp_forward(c, m->xemb, y.xemb, b->x, y.C0, N, y.cat, W, fuse_node_act(c)));
   }
+  // (readout split: see g_readout_split; the conditions are linear_bn's for statistics from the GEMM epilogue + a finalize launch)
+  const bool ro_split = g_readout_split && es.ok && !ss.ok && c.train && L >= 2 && fuse_node_act(c) && !sync_on(c) && g_gemm_stats && c.jobs != nullptr &&
+                        !(fold_ok(c, N) && H <= 256) && L * H <= 1280 &&
+                        esc_linear_fwd_from_ok(y.cat + L * H, W, m->lin1.w + L * H, W, N, H, H, 1) != 0;
   // GINE layers (reference :161, :167-175): xs[l+1] -> cat[:, (l+1)H : (l+2)H]
   for (int l = 0; l < L; ++l) {
     const esc_conv_t& cv = m->conv[l];
@@ -752,6 +762,11 @@ static int forward(const Ctx& c) {
       ESC_TRY(edge_term(l + ahead));
     }
     ESC_TRY(mlp_forward(c, cv.nn, y.conv[l], y.agg[l], C, N, y.cat + (int64_t)(l + 1) * H, W, fuse_node_act(c)));
+    if (ro_split && l == (int)L - 2) {        // slices 0 .. L-1 of cat (and their BatchNorm coefficients) are final: their share of lin1
+      ESC_TRY(chain(es.lin1_fork, (hipStream_t)c.s, es.stream));
+      ESC_TRY(esc_linear_fwd(y.cat, W, m->lin1.w, W, nullptr, y.cat_scale, y.cat_shift, N, H, L * H, y.Ypart, H, nullptr, es.stream));
+      if (hipEventRecord(es.lin1_rest, es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+    }
   }
   if (c.train) mark(PH_EDGE_FWD_DONE, ce.s);
   // readout (reference :183-189) needs every slice of cat, including the side stream's
@@ -765,6 +780,15 @@ static int forward(const Ctx& c) {
     return esc_linear_fwd_fold(y.Yl, H, m->lin2.w, H, m->lin2.b, &f, N, 1, H, y.pred, 1, nullptr, c.s);
   }
   const bool fa = fuse_node_act(c);       // cat holds pre-BatchNorm rows: the readout GEMM applies every slice's BatchNorm+ReLU itself
+  if (ro_split) {
+    const int64_t K0 = L * H;
+    if (hipStreamWaitEvent((hipStream_t)c.s, es.lin1_rest, 0) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
+    ESC_TRY(esc_linear_fwd_from(y.Ypart, H, y.cat + K0, W, m->lin1.w + K0, W, m->lin1.b, y.cat_scale + K0, y.cat_shift + K0, N, H, H, y.Yl, H,
+                                c.y.col_stats, c.s));
+    ESC_TRY(esc_bn_stats_from_partials_rows(c.y.col_stats, N, H, esc_linear_stats_block_rows(y.cat + K0, W, m->lin1.w + K0, W, N, H, H), m->bn_lin1.eps,
+                                            m->bn_lin1.momentum, y.bl.mean, y.bl.invstd, m->bn_lin1.running_mean, m->bn_lin1.running_var,
+                                            m->bn_lin1.gamma, m->bn_lin1.beta, y.bl.scale, y.bl.shift, c.s));
+  } else
   ESC_TRY(linear_bn(c, y.cat, W, m->lin1, fa ? y.cat_scale : nullptr, fa ? y.cat_shift : nullptr, N, y.Yl, m->bn_lin1, y.bl));
   return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
 }

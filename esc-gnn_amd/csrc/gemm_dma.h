@@ -85,6 +85,7 @@ struct GArgs {
   int M, N, R;                       // output rows, output cols, reduction length
   int red_per_split;                 // multiple of BK; splits = ceil(R / red_per_split)
   int accumulate;                    // C += ...
+  const float* c_init; int ld_init;  // forward tiles: start the accumulators from this [M, N] partial result (see gemm_body)
   int c_vec;                         // set by the launcher: 16-byte row stores are legal
   int ntile_m, ntile_n;              // set by the launcher
   unsigned long long* stamps;        // diagnostics (tools/gemm_lab): per workgroup clock readings, or null
@@ -359,6 +360,22 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // c_init: the tile starts from a partial result computed elsewhere (an earlier slice of the reduction: the readout Linear's columns
+  // of the layers that were already final) instead of from zero — statistics and bias then see the complete sums.  C/D map of the 32x32
+  // block: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h.
+  if (g.c_init != nullptr && !loader && !A_RM && !B_RM) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < g.M && col < g.N) acc[i][j][r] = g.c_init[(size_t)row * g.ld_init + col];
+        }
+      }
+  }
   float dbsum = 0.f;
   float dbfrag[(BNB && A_RM && DB) ? MT : 1] = {};          // BNB: per-lane column sums of the transformed A fragments
 

@@ -992,13 +992,14 @@ static void dma_wgrad_plan(int64_t M, int64_t N, int64_t K, int bm, int bn, int*
 }
 static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias, const float* in_scale,
                     const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y, float* col_stats,
-                    hipStream_t s, int* rc) {
+                    hipStream_t s, int* rc, const float* c_init = nullptr, int64_t ld_init = 0) {
   if (!(g_use_dma & 1) || K % 4 != 0 || K < 32 || !dma_ok(X, M, ld_x) || !dma_ok(W, N, ld_w) || (in_scale && cdiv(K, 32) * 32 > 1280)) return false;
   if (N <= 32 && (!(g_use_dma & 8) || col_stats != nullptr)) return false;
   dma::GArgs g{};
   g.A = X; g.lda = (int)ld_x; g.B = W; g.ldb = (int)ld_w; g.C = Y; g.ldc = (int)ld_y; g.bias = bias;
   g.pro_scale = in_scale; g.pro_shift = in_shift; g.col_stats = reinterpret_cast<float2*>(col_stats);
   g.M = (int)M; g.N = (int)N; g.R = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
+  g.c_init = c_init; g.ld_init = (int)ld_init;
   hipError_t e;
   if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
     e = in_scale ? dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 1, false, false>(g, 0, s)
@@ -1194,6 +1195,23 @@ int esc_linear_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, c
                    const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                    float* Y, int64_t ld_y, float* col_stats, void* stream) {
   return linear_fwd_impl(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, nullptr, stream);
+}
+
+/* Y = Y0 + act(X) W^T + b with the BatchNorm partials of the RESULT in col_stats: the second half of a Linear whose reduction was cut
+ * in two (see include/escgnn_hip.h).  LDS-DMA tiles only. */
+int esc_linear_fwd_from(const float* Y0, int64_t ld_y0, const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                        const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y,
+                        float* col_stats, void* stream) {
+  ESC_REQUIRE(Y0 && X && W && Y, "esc_linear_fwd_from: null pointer");
+  ESC_REQUIRE(M > 0 && N > 32 && K >= 32 && ld_y0 >= N && ld_x >= K && ld_w >= K && ld_y >= N && M < (1LL << 31), "esc_linear_fwd_from: bad sizes");
+  ESC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "esc_linear_fwd_from: in_scale/in_shift must come together");
+  int rc = ESC_OK;
+  ESC_REQUIRE(dma_fwd(X, ld_x, W, ld_w, bias, in_scale, in_shift, M, N, K, Y, ld_y, col_stats, (hipStream_t)stream, &rc, Y0, ld_y0),
+              "esc_linear_fwd_from: shape not served by the LDS-DMA tiles (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
+  return rc;
+}
+int esc_linear_fwd_from_ok(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, int has_prologue) {
+  return ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w) && !(has_prologue && cdiv(K, 32) * 32 > 1280)) ? 1 : 0;
 }
 
 int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,

@@ -189,6 +189,16 @@ typedef struct esc_bn_fuse {
   float* scale;              /* [N] out, may be NULL (together with shift) */
   float* shift;
 } esc_bn_fuse;
+/* Second half of a Linear whose reduction is cut in two: Y = Y0 + act(X) W^T + b, where Y0 [M, N] is what the first slice of the
+ * input columns contributed (esc_linear_fwd over those columns, no bias).  The accumulators START from Y0, so the BatchNorm partials
+ * in col_stats and the bias see the complete sums.  Used for the readout Linear over the layer concat (run_graphcount.py:183-185):
+ * the slices of the layers that are already final are reduced on the idle second stream while the last layer runs.  The result differs
+ * from the one-launch reduction in the order of the fp32 additions only (within the 1e-5 tolerance of north_star, tested).
+ * esc_linear_fwd_from_ok: the shape is served (LDS-DMA tiles). */
+int esc_linear_fwd_from(const float* Y0, int64_t ld_y0, const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
+                        const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K, float* Y, int64_t ld_y,
+                        float* col_stats, void* stream);
+int esc_linear_fwd_from_ok(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, int has_prologue);
 int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
                       const float* in_scale, const float* in_shift, int64_t M, int64_t N, int64_t K,
                       float* Y, int64_t ld_y, float* col_stats, const esc_bn_fuse* bn, void* stream);

@@ -319,6 +319,46 @@ def test_linear_with_fused_batchnorm_statistics(E, M, N, K, last_block):
     _chk(rvd, 0.9 * rv0.double() + 0.1 * r.var(0, unbiased=True), "running_var")
 
 
+@pytest.mark.parametrize("M,N,K0,K1,pro", [(2400, 256, 1024, 256, True), (333, 64, 96, 32, False), (2401, 256, 256, 256, True),
+                                          (15200, 256, 512, 256, True)])
+def test_linear_forward_cut_in_two_over_its_reduction(E, M, N, K0, K1, pro):
+    """esc_linear_fwd over the first K0 input columns (no bias) + esc_linear_fwd_from over the last K1 starting from that partial
+    result = the one-launch Linear over all K0 + K1 columns (run_graphcount.py:183-185, the readout over the layer concat): outputs
+    against fp64 and against the one-launch result (the same numbers up to the order of the fp32 additions), and the BatchNorm
+    partials of the epilogue describe the COMPLETE sums (same mean / invstd as the one-launch partials)."""
+    nv = E._native
+    torch.manual_seed(M + K0)
+    dev = torch.device("cuda:0")
+    K = K0 + K1
+    x, w, bias = torch.randn(M, K) + 0.3, torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    sc, sh = torch.rand(K) + 0.5, torch.randn(K) * 0.2
+    xd, wd, bd, scd, shd = (t.to(dev).contiguous() for t in (x, w, bias, sc, sh))
+    a = torch.relu(x.double() * sc.double() + sh.double()) if pro else x.double()
+    want = a @ w.double().t() + bias.double()
+    p_sc = (lambda off: scd.data_ptr() + 4 * off) if pro else (lambda off: None)
+    p_sh = (lambda off: shd.data_ptr() + 4 * off) if pro else (lambda off: None)
+    nstat = ((M + 31) // 32) * N * 2
+    one, st_one = torch.empty(M, N, device=dev), torch.zeros(nstat, device=dev)
+    nv.call("esc_linear_fwd", nv.ptr(xd), K, nv.ptr(wd), K, nv.ptr(bd), p_sc(0), p_sh(0), M, N, K, nv.ptr(one), N, nv.ptr(st_one), nv.stream())
+    assert nv.lib().esc_linear_fwd_from_ok(xd.data_ptr() + 4 * K0, K, wd.data_ptr() + 4 * K0, K, M, N, K1, int(pro)) == 1
+    part, two, st_two = torch.empty(M, N, device=dev), torch.full((M, N), float("nan"), device=dev), torch.zeros(nstat, device=dev)
+    nv.call("esc_linear_fwd", nv.ptr(xd), K, nv.ptr(wd), K, None, p_sc(0), p_sh(0), M, N, K0, nv.ptr(part), N, None, nv.stream())
+    nv.call("esc_linear_fwd_from", nv.ptr(part), N, xd.data_ptr() + 4 * K0, K, wd.data_ptr() + 4 * K0, K, nv.ptr(bd), p_sc(K0), p_sh(K0),
+            M, N, K1, nv.ptr(two), N, nv.ptr(st_two), nv.stream())
+    _chk(two, want, "two launches vs fp64")
+    assert float((two - one).abs().max()) <= 1e-5 * float(one.abs().max()), "two launches vs one"
+    outs = []
+    for st, k in ((st_one, K), (st_two, K1)):
+        mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        br = nv.lib().esc_linear_stats_block_rows(nv.ptr(xd), K, nv.ptr(wd), K, M, N, k)
+        nv.call("esc_bn_stats_from_partials_rows", nv.ptr(st), M, N, br, 1e-5, 0.1, nv.ptr(mean), nv.ptr(invstd), None, None, None, None, None,
+                None, nv.stream())
+        outs.append((mean, invstd))
+    _chk(outs[1][0], want.mean(0), "mean of the complete sums")
+    _chk(outs[1][1], 1 / torch.sqrt(want.var(0, unbiased=False) + 1e-5), "invstd of the complete sums")
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (2401, 256, 10), (333, 64, 64), (15200, 256, 256), (97, 128, 1280),
                                    (333, 64, 300)])
 def test_batchnorm_folded_into_its_consumer(E, M, N, K):
