@@ -684,6 +684,45 @@ def test_embed_plan_arrays(E, n, dims):
         E.ops.embed_plan(torch.zeros(4, k + 1, dtype=torch.int64, device=dev), dims)
 
 
+def test_scatter_add_execution_window_on_the_device_clock(E):
+    """esc_prof_span_arm / _read: the armed launches of the scatter-add run the stamped instantiation (same result, bit for bit) and
+    report a positive execution window that is no longer than the event pair of the same launch (pair = dispatch gap + kernel);
+    launches beyond the armed count carry no stamps."""
+    from esc_gnn_amd import _native as nv
+    dev = torch.device("cuda:0")
+    b = _batch()
+    plan = _plan(E, b, dev)
+    N, Ee, C = plan.num_nodes, plan.num_edges, 256
+    g0 = torch.Generator().manual_seed(11)
+    x, e = torch.randn(N, C, generator=g0).to(dev), torch.randn(Ee, C, generator=g0).to(dev)
+    sc, sh = (torch.rand(C, generator=g0) + 0.5).to(dev), torch.randn(C, generator=g0).to(dev)
+    eps = torch.tensor([0.3], device=dev)
+    s = nv.stream()
+
+    def run():
+        out = torch.empty(N, C, device=dev)
+        nv.call("esc_gine_aggregate_fwd_affine", nv.ptr(x), C, nv.ptr(sc), nv.ptr(sh), nv.ptr(e), C, nv.ptr(plan.in_ptr), nv.ptr(plan.in_edge),
+                nv.ptr(plan.in_src), nv.ptr(eps), N, C, nv.ptr(out), C, s)
+        return out
+    want = run()
+    nv.prof_reset("agg_fwd")
+    nv.prof_span_arm("agg_fwd", 2)
+    nv.prof_enable("agg_fwd", True)
+    try:
+        outs = [run() for _ in range(3)]
+        torch.cuda.synchronize()
+    finally:
+        nv.prof_enable("agg_fwd", False)
+    for o in outs:
+        assert torch.equal(o, want)
+    spans = nv.prof_span_read("agg_fwd")
+    pairs = [1e3 * ms for ms in nv.prof_read_all("agg_fwd")]
+    assert len(spans) == 2 and len(pairs) == 3                 # the third launch was not armed
+    for sp, pr in zip(spans, pairs):
+        assert 0.0 < sp <= pr + 0.5, (sp, pr)
+    nv.prof_reset("agg_fwd")
+
+
 def test_aggregate_with_on_the_fly_batchnorm_relu_matches_the_materialised_path(E):
     """esc_gine_aggregate_fwd_affine / _bwd_affine (the layer input given as pre-BatchNorm rows + (scale, shift)) against
     esc_affine_act followed by the plain aggregate kernels: forward BIT-identical (same fmaf + max, same summation order),
