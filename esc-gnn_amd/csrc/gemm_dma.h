@@ -188,7 +188,7 @@ __device__ __forceinline__ void dma_offsets(int (&vo)[NP], int (&kc)[NP], int dw
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB, bool INIT = false>
 __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ lds, int wg) {
   using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
   constexpr int NW = C_::NW, DW = C_::DW;
@@ -362,8 +362,9 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // c_init: the tile starts from a partial result computed elsewhere (an earlier slice of the reduction: the readout Linear's columns
   // of the layers that were already final) instead of from zero — statistics and bias then see the complete sums.  C/D map of the 32x32
-  // block: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h.
-  if (g.c_init != nullptr && !loader && !A_RM && !B_RM) {
+  // block: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h.  (Its own instantiation: with the loads in the common kernels the
+  // compiler keeps the accumulators in 60-100 more VGPRs — 135 -> 194 for the edge-row tile — and every forward GEMM pays.)
+  if constexpr (INIT) if (g.c_init != nullptr && !loader) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -752,11 +753,11 @@ __device__ __forceinline__ void gemm_body(const GArgs& g, float* __restrict__ ld
   stamp(g.stamps, 3);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB, bool INIT = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_kernel(GArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if constexpr (BM * BN < 128 * 128) ESC_PRIO();            // node-sized tiles: see common.h
-  gemm_body<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>(g, lds, (int)blockIdx.x);
+  gemm_body<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB, INIT>(g, lds, (int)blockIdx.x);
 }
 
 // Backward of one Linear in ONE launch: the first workgroups compute the dX tiles (NN), the rest the split-M dW slabs
@@ -794,10 +795,10 @@ inline void finish_args(GArgs& g) {
   if (g.red_per_split <= 0 || g.red_per_split > g.R) g.red_per_split = g.R;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int LW, bool A_RM, bool B_RM, int PRO, bool STATS, bool DB, bool INIT = false>
 inline hipError_t launch_gemm(GArgs g, size_t lds_floor, hipStream_t s, int kind = ESC_K_LINEAR) {
   using C_ = Cfg<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
-  auto kern = gemm_kernel<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB>;
+  auto kern = gemm_kernel<BM, BN, BK, WM, WN, STAGES, LW, A_RM, B_RM, PRO, STATS, DB, INIT>;
   if (BM < 128 && gemm_lds_floor() == 0 && (size_t)node_lds_floor() > lds_floor) lds_floor = (size_t)node_lds_floor();
   const size_t lds = C_::LDS_BYTES > lds_floor ? C_::LDS_BYTES : lds_floor;
   static size_t raised_to = 64 * 1024;      // per instantiation

@@ -1001,6 +1001,15 @@ static bool dma_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, 
   g.M = (int)M; g.N = (int)N; g.R = (int)K; g.red_per_split = (int)K; g.accumulate = 0;
   g.c_init = c_init; g.ld_init = (int)ld_init;
   hipError_t e;
+  if (c_init != nullptr) {         // esc_linear_fwd_from: the instantiations whose accumulators start from a partial result
+    if (N <= 32 || !tile128_ok(N) && dma_big(M, N)) return false;
+    if (dma_big(M, N)) e = in_scale ? dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 1, true, false, true>(g, 0, s)
+                                    : dma::launch_gemm<128, 128, 32, 2, 2, 3, 4, false, false, 0, true, false, true>(g, 0, s);
+    else               e = in_scale ? dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 1, true, false, true>(g, 0, s)
+                                    : dma::launch_gemm<64, 64, 32, 2, 2, 3, 2, false, false, 0, true, false, true>(g, 0, s);
+    *rc = dma_check(e, "esc_linear_fwd_from") == hipSuccess ? ESC_OK : ESC_ELAUNCH;
+    return true;
+  }
   if (N <= 32) {                   // narrow outputs (GINEConv.lin 256 -> 10): a 64x32 tile, bandwidth-bound on X
     e = in_scale ? dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 1, false, false>(g, 0, s)
                  : dma::launch_gemm<64, 32, 32, 2, 1, 3, 2, false, false, 0, false, false>(g, 0, s);
@@ -1211,7 +1220,8 @@ int esc_linear_fwd_from(const float* Y0, int64_t ld_y0, const float* X, int64_t 
   return rc;
 }
 int esc_linear_fwd_from_ok(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, int has_prologue) {
-  return ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w) && !(has_prologue && cdiv(K, 32) * 32 > 1280)) ? 1 : 0;
+  return ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w) && !(has_prologue && cdiv(K, 32) * 32 > 1280) &&
+          !(dma_big(M, N) && !tile128_ok(N))) ? 1 : 0;
 }
 
 int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,
