@@ -691,10 +691,10 @@ static int forward(const Ctx& c) {
     if (es.ok && hipEventRecord(es.e_ready[0], es.stream) != hipSuccess) { set_error("esc_engine: stream event failed"); return ESC_ELAUNCH; }
   }
   if (mat) ESC_TRY(esc_affine_act(y.Yz, H, E, H, y.zb1.scale, y.zb1.shift, 1, y.Zemb, H, ce.s));
-  // The edge terms run one layer ahead of the node chain: e_{l+1} is queued behind the aggregate of layer l and overlaps
-  // that layer's MLP, so that a bandwidth-bound aggregate never shares the HBM with an edge-sized GEMM (both would only
-  // slow each other down) — measured against two layers ahead: 1.255 -> 1.225 ms with the occupancy cap, and the
-  // scatter-add back at 59 % of the HBM peak by the bench's clock.
+  // Per-layer launches (ESC_EDGE_BATCHED=0, L < 3, or activations not materialised): the edge terms run one layer ahead of the node
+  // chain — e_{l+1} is queued behind the aggregate of layer l and overlaps that layer's MLP, so that a bandwidth-bound aggregate never
+  // shares the HBM with an edge-sized GEMM (r01: 1.255 -> 1.225 ms against two layers ahead).  The default since r03 is the batched
+  // launch below.
   auto edge_term = [&](int l) -> int {
     const LdsFloorGuard cap(ce.on_edge_stream && g_cap_forward);
     const esc_conv_t& cv = m->conv[l];
