@@ -69,6 +69,7 @@ struct Layout {
 // The readout Linear reduces over all (L+1)*H concat columns (K = 1280: 152 workgroups walking 40 K-steps, 33 us — the longest kernel of
 // the node forward).  L of its L+1 slices are final before the LAST layer starts: their share is computed on the idle edge stream while
 // that layer runs, and the launch on the node chain starts from it and only reduces over the last slice (esc_linear_fwd_from).
+static int g_ogb_bnb = getenv("ESC_OGB_BNB") ? atoi(getenv("ESC_OGB_BNB")) : 0;
 static int g_readout_split = getenv("ESC_READOUT_SPLIT") ? atoi(getenv("ESC_READOUT_SPLIT")) : 0;    // measured neutral (1.012-1.016 ms either way): off
 static int g_skip_waits = getenv("ESC_SKIP_WAITS") ? atoi(getenv("ESC_SKIP_WAITS")) : 1;   // -7 us of step time
 static int g_edge_batched = getenv("ESC_EDGE_BATCHED") ? atoi(getenv("ESC_EDGE_BATCHED")) : 1;
@@ -1483,7 +1484,7 @@ static int backward_ogb(const OgbCtx& z) {
     ESC_TRY(bn_backward_drop(last ? c0 : c, w.hc, H, dH, H, N, w.bn, q.bn, w.mask_h, p, 0, y.dT, H, y.bn_scratch));
     // The hidden BatchNorm's backward loses its partial-sum pass (2H-wide rows: the most expensive of its three launches): the
     // column sums come out of lin1's dX epilogue (esc_linear_bwd_both_bn with bn == NULL), then finalize + apply
-    bool hidden_done = false;
+    bool hidden_done = false, hidden_fused = false;
     if (g_ogb_prologue && (g_bn_fuse_bwd & 2) && !sync_on(c) && y.bst_part != nullptr) {
       const esc_bn_bwd_next n0{y.bst_part, w.Y0, H2, w.b0.mean, w.b0.invstd, w.b0.scale, w.b0.shift, 1};
       const float* slab_probe = c.jobs ? *c.slab_cursor : c.y.slabs;
@@ -1500,7 +1501,18 @@ static int backward_ogb(const OgbCtx& z) {
                                        q.lin1.db, slabs, job, &n0, c.s));
         ESC_TRY(esc_bn_bwd_coef_from_partials(y.bst_part, cdiv(N, esc_linear_bwd_bn_block_rows(N, H, H2)), N, H2, w.b0.coef, q.bn0.dgamma,
                                               q.bn0.dbeta, c.s));
-        ESC_TRY(esc_bn_bwd_apply(w.Y0, H2, nullptr, 0, y.dA1, H2, N, H2, w.b0.mean, w.b0.invstd, q.bn0.gamma, q.bn0.beta, 1, w.b0.coef, y.dA1, H2, c.s));
+        // the apply of the hidden BatchNorm's backward rides on lin0's dX+dW launch (operand staging) when the fused kernels serve the shape
+        // (ESC_OGB_BNB=1; measured below)
+        {
+          const esc_bn_bwd_fused f0 = bn_fused(w.Y0, H2, w.b0, 1);
+          const float* probe = c.jobs ? *c.slab_cursor : c.y.slabs;
+          if (g_ogb_bnb && esc_linear_bwd_both_bn_ok(y.dA1, H2, &f0, w.agg, H, q.lin0.w, H, N, H2, H, y.dagg, H, probe, nullptr)) {
+            ESC_TRY(linear_backward_bn(c, y.dA1, H2, f0, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0, nullptr));
+            hidden_fused = true;
+          } else {
+            ESC_TRY(esc_bn_bwd_apply(w.Y0, H2, nullptr, 0, y.dA1, H2, N, H2, w.b0.mean, w.b0.invstd, q.bn0.gamma, q.bn0.beta, 1, w.b0.coef, y.dA1, H2, c.s));
+          }
+        }
         hidden_done = true;
       }
     }
@@ -1509,7 +1521,7 @@ static int backward_ogb(const OgbCtx& z) {
       else                ESC_TRY(linear_backward(c, y.dT, H, w.A1, H2, nullptr, nullptr, q.lin1, N, y.dA1, H2, 0));
       ESC_TRY(bn_backward(c, w.Y0, H2, nullptr, 0, y.dA1, H2, N, w.b0, q.bn0, y.dA1, H2, y.bn_scratch, H2));      // (ReLU mask from the pre-BatchNorm rows: A1 is not re-read)
     }
-    ESC_TRY(linear_backward(c, y.dA1, H2, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0));
+    if (!hidden_fused) ESC_TRY(linear_backward(c, y.dA1, H2, w.agg, H, nullptr, nullptr, q.lin0, N, y.dagg, H, 0));
     // virtual-node update of this layer: vn_{l+1} = dropout(mlp(add_pool(hin) + vn_l)) (+ vn_l)
     bool have_dhin = false;
     if (!last) {

@@ -7,6 +7,9 @@ from esc_gnn_amd.datasets import synthetic_zinc_graphs, build_feature_dataset
 from esc_gnn_amd.zinc_models import NestedGIN_eff as ZincModel
 from esc_gnn_amd.engine import ZincStepEngine
 DEV = 'cuda:0'
+if os.environ.get('ESC_TWO_MIN'):
+    from esc_gnn_amd import _native as _nv
+    _nv.call('esc_engine_set_two_stream_min_edges', int(os.environ['ESC_TWO_MIN']))
 og = build_feature_dataset(synthetic_zinc_graphs(0, 1024), 3, use_rd=True, self_loop=False)
 store = E.DeviceGraphStore(og, DEV)
 bs = 128
