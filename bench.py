@@ -10,6 +10,11 @@ A "step" = one pass of the hot path over one batch: device collate + forward + L
 (random regular graphs, h=3, rd + self loops, bs=128 PER GPU, L=4, H=256).  The pre-processed
 dataset (features from the HIP feature builder) is resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.
+
+`roofline` = the scatter-add (esc::agg_fwd_wave): algorithmic bytes per launch / the launch's execution window, measured live in
+the timed region on the device wall clock (first workgroup in -> last wave out, esc_prof_span_*); the hipExtLaunchKernelGGL event
+pairs of all launches (= inter-kernel dispatch gap + kernel) and the committed rocprofv3 trace's average stand beside it
+(`event_pairs`, `rocprofv3_avg_us`; DESIGN.md section 5 has the evidence for that choice of clock).
 """
 import argparse
 import json
