@@ -77,6 +77,8 @@ SIGNATURES = {
     "esc_segment_pool_bwd": [P, I64, P, I64, I64, I32, P, I64, P],
     "esc_linear_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
     "esc_linear_bn_fwd": [P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, POINTER(BnFuse), P],
+    "esc_linear_fwd_l1": [P, I64, P, P, P, P, I64, I64, P, I64, F32, P, P, P],
+    "esc_linear_fwd_l1_ok": [P, I64, P, I64, P, P],
     "esc_linear_fwd_from": [P, I64, P, I64, P, I64, P, P, P, I64, I64, I64, P, I64, P, P],
     "esc_linear_fwd_from_ok": [P, I64, P, I64, I64, I64, I64, I32],
     "esc_linear_stats_block_rows": [P, I64, P, I64, I64, I64, I64],

@@ -69,6 +69,7 @@ struct Layout {
 // The readout Linear reduces over all (L+1)*H concat columns (K = 1280: 152 workgroups walking 40 K-steps, 33 us — the longest kernel of
 // the node forward).  L of its L+1 slices are final before the LAST layer starts: their share is computed on the idle edge stream while
 // that layer runs, and the launch on the node chain starts from it and only reduces over the last slice (esc_linear_fwd_from).
+static int g_l1_head = getenv("ESC_L1_HEAD") ? atoi(getenv("ESC_L1_HEAD")) : 1;     // see train_step_impl()
 static int g_ogb_bnb = getenv("ESC_OGB_BNB") ? atoi(getenv("ESC_OGB_BNB")) : 0;
 static int g_readout_split = getenv("ESC_READOUT_SPLIT") ? atoi(getenv("ESC_READOUT_SPLIT")) : 0;    // measured neutral (1.012-1.016 ms either way): off
 static int g_skip_waits = getenv("ESC_SKIP_WAITS") ? atoi(getenv("ESC_SKIP_WAITS")) : 1;   // -7 us of step time
@@ -151,6 +152,8 @@ struct Ctx {
   bool on_edge_stream = false;
   int act = 1;                                   // 1 ReLU (counting model), 2 ELU (ZINC): materialised activations
   void* wgrad = nullptr;                         // != NULL: the node chain's weight-gradient tiles go to this stream (backward())
+  const float* l1_target = nullptr;              // train_step: the prediction head also leaves d L1 / d pred (forward(), g_l1_head)
+  int64_t l1_denom = 0;
 };
 // While it lives, node-sized Linear backwards launched for `c` put their dW tiles on c.wgrad (esc_linear_bwd_set_wgrad_stream)
 struct WgradScope {
@@ -791,6 +794,10 @@ static int forward(const Ctx& c) {
                                             m->bn_lin1.gamma, m->bn_lin1.beta, y.bl.scale, y.bl.shift, c.s));
   } else
   ESC_TRY(linear_bn(c, y.cat, W, m->lin1, fa ? y.cat_scale : nullptr, fa ? y.cat_shift : nullptr, N, y.Yl, m->bn_lin1, y.bl));
+  // train_step: the head's launch leaves the L1 gradient of every prediction too, so the backward starts behind it and the loss
+  // launch (a single workgroup walking all predictions, 5-7 us) leaves the chain
+  if (c.l1_target != nullptr && esc_linear_fwd_l1_ok(y.Yl, H, m->lin2.w, H, y.bl.scale, y.bl.shift))
+    return esc_linear_fwd_l1(y.Yl, H, m->lin2.w, m->lin2.b, y.bl.scale, y.bl.shift, N, H, c.l1_target, c.l1_denom, 1.0f, y.pred, y.dpred, c.s);
   return esc_linear_fwd(y.Yl, H, m->lin2.w, H, m->lin2.b, y.bl.scale, y.bl.shift, N, 1, H, y.pred, 1, nullptr, c.s);
 }
 
@@ -1742,8 +1749,18 @@ static int train_step_impl(const esc_nested_gin_t* m, const esc_batch_t* b, floa
   jobs.reserve(ESC_MAX_REDUCE_JOBS);
   float* cursor = c.y.slabs;
   if (3 * m->num_layers + 7 <= ESC_MAX_REDUCE_JOBS) { c.jobs = &jobs; c.slab_cursor = &cursor; }
+  const int64_t denom = loss_denom > 0 ? loss_denom : b->N;
+  EdgeStream& es = edge_stream_for(b->E);
+  const bool head_l1 = g_l1_head && es.ok && m->hidden <= 1024 &&
+                       esc_linear_fwd_l1_ok(c.y.Yl, m->hidden, m->lin2.w, m->hidden, c.y.bl.scale, c.y.bl.shift) != 0;
+  if (head_l1) { c.l1_target = b->y; c.l1_denom = denom; }
   ESC_TRY(forward(c));
-  ESC_TRY(esc_l1_loss(c.y.pred, b->y, b->N, loss_denom > 0 ? loss_denom : b->N, 1.0f, loss, c.y.dpred, stream));
+  if (head_l1) {              // the loss VALUE: on the edge stream (idle here), ordered behind the head; the step's join covers it
+    ESC_TRY(chain(es.lin1_fork, (hipStream_t)stream, es.stream));
+    ESC_TRY(esc_l1_loss(c.y.pred, b->y, b->N, denom, 1.0f, loss, nullptr, es.stream));
+  } else {
+    ESC_TRY(esc_l1_loss(c.y.pred, b->y, b->N, denom, 1.0f, loss, c.y.dpred, stream));
+  }
   mark(PH_NODE_FWD_DONE, stream);
   if (pred) {
     if (hipMemcpyAsync(pred, c.y.pred, sizeof(float) * (size_t)b->N, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {

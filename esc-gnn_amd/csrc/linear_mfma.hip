@@ -744,13 +744,16 @@ static inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && (l
 constexpr int NARROW_N = 4, NARROW_K = 256;                      // measured: at N = 10 the wave reductions cost more than the padded MFMA tile
 constexpr int NARROW_ROWS = 32;                                  // rows per workgroup of linear_narrow_bwd: 2 400 rows = 75 workgroups (128 left 19 on 256 CUs)
 
-template <int NMAX, bool PRO, bool FOLD = false>
+// L1: the H -> 1 prediction head of a training step — the wave that has a node's prediction also leaves d|pred - y| / d pred for it
+// (the same expression as l1_loss_kernel), so the backward does not wait for the loss launch
+struct NarrowL1 { const float* target; float gs; float* dpred; };
+template <int NMAX, bool PRO, bool FOLD = false, bool L1 = false>
 __global__ __launch_bounds__(256) void linear_narrow_fwd(const float* __restrict__ X, int64_t ldx,
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ sc, const float* __restrict__ sh,
                                                          int M, int N, int K, float* __restrict__ Y, int64_t ldy,
-                                                         BnFoldDev fold) {
+                                                         BnFoldDev fold, NarrowL1 l1) {
   ESC_PRIO();
   const int lane = lane_id();
   const int k = lane * 4;
@@ -797,6 +800,12 @@ __global__ __launch_bounds__(256) void linear_narrow_fwd(const float* __restrict
         }
       }
       if (lane < N) Y[(size_t)r * ldy + lane] = mine + bv;
+      if constexpr (L1) {
+        if (lane == 0) {
+          const float d = (mine + bv) - l1.target[r];
+          l1.dpred[r] = d > 0.f ? l1.gs : (d < 0.f ? -l1.gs : 0.f);
+        }
+      }
     }
   }
 }
@@ -1103,8 +1112,8 @@ static int linear_fwd_impl(const float* X, int64_t ld_x, const float* W, int64_t
   if (col_stats == nullptr && narrow_ok(N, K, X, ld_x, W, ld_w, in_scale, in_shift)) {
     const unsigned blocks = (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048);      // 4 rows per wave and pass
 #define ESC_NARROW_FWD(NM) \
-    if (in_scale) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y, BnFoldDev{}); \
-    else          esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, false>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y, BnFoldDev{})
+    if (in_scale) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y, BnFoldDev{}, NarrowL1{}); \
+    else          esc::launch(ESC_K_LINEAR, linear_narrow_fwd<NM, false>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, in_scale, in_shift, (int)M, (int)N, (int)K, Y, ld_y, BnFoldDev{}, NarrowL1{})
     if (N == 1) { ESC_NARROW_FWD(1); } else { ESC_NARROW_FWD(4); }
 #undef ESC_NARROW_FWD
     ESC_CHECK_LAUNCH("esc_linear_fwd.narrow");
@@ -1184,8 +1193,8 @@ int esc_linear_fwd_fold(const float* X, int64_t ld_x, const float* W, int64_t ld
               in_bn->scale, in_bn->shift, in_bn->running_mean, in_bn->running_var};
   if (col_stats == nullptr && N <= NARROW_N && K <= NARROW_K && K % 4 == 0 && vec_ok(X, ld_x) && vec_ok(W, ld_w)) {
     const unsigned blocks = (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048);
-    if (N == 1) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<1, true, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, (const float*)nullptr, (const float*)nullptr, (int)M, (int)N, (int)K, Y, ld_y, f);
-    else        esc::launch(ESC_K_LINEAR, linear_narrow_fwd<4, true, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, (const float*)nullptr, (const float*)nullptr, (int)M, (int)N, (int)K, Y, ld_y, f);
+    if (N == 1) esc::launch(ESC_K_LINEAR, linear_narrow_fwd<1, true, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, (const float*)nullptr, (const float*)nullptr, (int)M, (int)N, (int)K, Y, ld_y, f, NarrowL1{});
+    else        esc::launch(ESC_K_LINEAR, linear_narrow_fwd<4, true, true>, dim3(blocks), dim3(256), 0, s, X, ld_x, W, ld_w, bias, (const float*)nullptr, (const float*)nullptr, (int)M, (int)N, (int)K, Y, ld_y, f, NarrowL1{});
     ESC_CHECK_LAUNCH("esc_linear_fwd_fold.narrow");
     return ESC_OK;
   }
@@ -1222,6 +1231,25 @@ int esc_linear_fwd_from(const float* Y0, int64_t ld_y0, const float* X, int64_t 
 int esc_linear_fwd_from_ok(const float* X, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int64_t N, int64_t K, int has_prologue) {
   return ((g_use_dma & 1) && K % 4 == 0 && K >= 32 && N > 32 && dma_ok(X, M, ld_x) && dma_ok(W, N, ld_w) && !(has_prologue && cdiv(K, 32) * 32 > 1280) &&
           !(dma_big(M, N) && !tile128_ok(N))) ? 1 : 0;
+}
+
+/* pred = act(X) w^T + b for ONE output column (the H -> 1 head) and, in the same launch, dpred = d(sum |pred - target| * grad_scale /
+ * denom) / d pred — what esc_l1_loss would leave in its dpred (same expression, bit for bit); see include/escgnn_hip.h */
+int esc_linear_fwd_l1(const float* X, int64_t ld_x, const float* w, const float* bias, const float* in_scale, const float* in_shift,
+                      int64_t M, int64_t K, const float* target, int64_t denom, float grad_scale, float* pred, float* dpred, void* stream) {
+  ESC_REQUIRE(X && w && target && pred && dpred, "esc_linear_fwd_l1: null pointer");
+  ESC_REQUIRE(M > 0 && K > 0 && ld_x >= K && denom > 0 && M < (1LL << 31), "esc_linear_fwd_l1: bad sizes");
+  ESC_REQUIRE(in_scale != nullptr && in_shift != nullptr, "esc_linear_fwd_l1: the head reads pre-BatchNorm rows (in_scale / in_shift)");
+  ESC_REQUIRE(narrow_ok(1, K, X, ld_x, w, K, in_scale, in_shift), "esc_linear_fwd_l1: shape / alignment not served (K=%ld)", (long)K);
+  const unsigned blocks = (unsigned)(cdiv(M, 16) < 2048 ? cdiv(M, 16) : 2048);
+  const NarrowL1 l1{target, (float)((double)grad_scale / (double)denom), dpred};
+  esc::launch(ESC_K_LINEAR, linear_narrow_fwd<1, true, false, true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ld_x, w, K, bias, in_scale,
+              in_shift, (int)M, 1, (int)K, pred, (int64_t)1, BnFoldDev{}, l1);
+  ESC_CHECK_LAUNCH("esc_linear_fwd_l1");
+  return ESC_OK;
+}
+int esc_linear_fwd_l1_ok(const float* X, int64_t ld_x, const float* w, int64_t K, const float* in_scale, const float* in_shift) {
+  return (in_scale && in_shift && narrow_ok(1, K, X, ld_x, w, K, in_scale, in_shift)) ? 1 : 0;
 }
 
 int esc_linear_bn_fwd(const float* X, int64_t ld_x, const float* W, int64_t ld_w, const float* bias,

@@ -189,6 +189,12 @@ typedef struct esc_bn_fuse {
   float* scale;              /* [N] out, may be NULL (together with shift) */
   float* shift;
 } esc_bn_fuse;
+/* The H -> 1 prediction head of a training step (run_graphcount.py:186-189 followed by F.l1_loss, :499): pred = relu(x*scale+shift) w^T + b
+ * and, in the same launch, dpred[i] = sign(pred[i] - target[i]) * grad_scale / denom — exactly what esc_l1_loss leaves in its dpred —
+ * so that the backward does not wait for the loss launch (whose value can then be computed on another stream). */
+int esc_linear_fwd_l1(const float* X, int64_t ld_x, const float* w, const float* bias, const float* in_scale, const float* in_shift,
+                      int64_t M, int64_t K, const float* target, int64_t denom, float grad_scale, float* pred, float* dpred, void* stream);
+int esc_linear_fwd_l1_ok(const float* X, int64_t ld_x, const float* w, int64_t K, const float* in_scale, const float* in_shift);
 /* Second half of a Linear whose reduction is cut in two: Y = Y0 + act(X) W^T + b, where Y0 [M, N] is what the first slice of the
  * input columns contributed (esc_linear_fwd over those columns, no bias).  The accumulators START from Y0, so the BatchNorm partials
  * in col_stats and the bias see the complete sums.  Used for the readout Linear over the layer concat (run_graphcount.py:183-185):

@@ -319,6 +319,29 @@ def test_linear_with_fused_batchnorm_statistics(E, M, N, K, last_block):
     _chk(rvd, 0.9 * rv0.double() + 0.1 * r.var(0, unbiased=True), "running_var")
 
 
+@pytest.mark.parametrize("M,K", [(2400, 256), (333, 64), (5, 128)])
+def test_prediction_head_leaves_the_l1_gradient(E, M, K):
+    """esc_linear_fwd_l1 (the H -> 1 head of a training step) = esc_linear_fwd with the BatchNorm+ReLU prologue followed by
+    esc_l1_loss's dpred: predictions and gradient identical bit for bit (ties pred == target give 0 like torch's sign)."""
+    nv = E._native
+    torch.manual_seed(M + K)
+    dev = torch.device("cuda:0")
+    x, w, b = torch.randn(M, K).to(dev), (torch.randn(1, K) / K ** 0.5).to(dev), torch.randn(1).to(dev)
+    sc, sh = (torch.rand(K) + 0.5).to(dev), (torch.randn(K) * 0.3).to(dev)
+    want_pred = torch.empty(M, device=dev)
+    nv.call("esc_linear_fwd", nv.ptr(x), K, nv.ptr(w), K, nv.ptr(b), nv.ptr(sc), nv.ptr(sh), M, 1, K, nv.ptr(want_pred), 1, None, nv.stream())
+    y = torch.randn(M, device=dev)
+    y[::7] = want_pred[::7]                                          # exact ties
+    loss, want_d = torch.empty(1, device=dev), torch.empty(M, device=dev)
+    nv.call("esc_l1_loss", nv.ptr(want_pred), nv.ptr(y), M, M, 1.0, nv.ptr(loss), nv.ptr(want_d), nv.stream())
+    assert nv.lib().esc_linear_fwd_l1_ok(nv.ptr(x), K, nv.ptr(w), K, nv.ptr(sc), nv.ptr(sh)) == 1
+    pred, d = torch.full((M,), float("nan"), device=dev), torch.full((M,), float("nan"), device=dev)
+    nv.call("esc_linear_fwd_l1", nv.ptr(x), K, nv.ptr(w), nv.ptr(b), nv.ptr(sc), nv.ptr(sh), M, K, nv.ptr(y), M, 1.0, nv.ptr(pred), nv.ptr(d),
+            nv.stream())
+    assert torch.equal(pred, want_pred) and torch.equal(d, want_d)
+    assert float(d[::7].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,N,K0,K1,pro", [(2400, 256, 1024, 256, True), (333, 64, 96, 32, False), (2401, 256, 256, 256, True),
                                           (15200, 256, 512, 256, True)])
 def test_linear_forward_cut_in_two_over_its_reduction(E, M, N, K0, K1, pro):
