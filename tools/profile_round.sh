@@ -37,7 +37,8 @@ cat "$OUT/${TAG}_bench.json.log"
 python3 - "$OUT/${TAG}_bench_kernel_stats.csv" "$OUT/${TAG}_bench_under_rocprof.json.log" "$OUT/${TAG}_bench.json.log" > "$OUT/${TAG}_roofline_check.txt" <<'PY' || true
 import csv, json, sys
 rows = {r["Name"]: r for r in csv.DictReader(open(sys.argv[1]))}
-agg = next((r for n, r in rows.items() if "agg_fwd_wave<2" in n), None)
+agg = next((r for n, r in rows.items() if "agg_fwd_wave<2, true, false>" in n), None) or next((r for n, r in rows.items() if "agg_fwd_wave<2" in n), None)
+agg_st = next((r for n, r in rows.items() if "agg_fwd_wave<2, true, true>" in n), None)       # the stamped instantiation (the armed launches)
 line = json.loads(open(sys.argv[2]).read())
 plain = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
 rf = line["roofline"]; alg = rf["alg_bytes_per_launch"]
@@ -45,7 +46,10 @@ print("kernel esc::agg_fwd_wave<2, true> (the wide scatter-add launches of the s
 t = float(agg["AverageNs"]) * 1e-3
 print("  traced run, rocprofv3 kernel stats        : %d calls, average %.2f us -> %.0f GB/s = %.3f of 8 TB/s" % (int(agg["Calls"]), t, alg / t / 1e3, alg / t / 1e3 / 8000))
 ep = rf.get("event_pairs", rf)
-print("  traced run, in-kernel window (bench.py)   : %d launches, average %.2f us -> frac %.3f  <- the live clock and rocprofv3 in the SAME run: %.0f %% apart (the window excludes the launch ramp)" % (rf["launches"], rf["avg_us"], rf["frac"], abs(rf["avg_us"] - t) / t * 100))
+ts = float(agg_st["AverageNs"]) * 1e-3 if agg_st else t
+if agg_st:
+    print("  traced run, rocprofv3, stamped launches   : %d calls, average %.2f us (the instantiation with the clock stamps, launched for the armed launches only)" % (int(agg_st["Calls"]), ts))
+print("  traced run, in-kernel window (bench.py)   : %d launches, average %.2f us -> frac %.3f  <- the live clock against rocprofv3's dispatch begin -> end of the SAME launches: %.2f us = %.0f %% shorter (launch ramp and end-of-kernel processing are outside the window)" % (rf["launches"], rf["avg_us"], rf["frac"], ts - rf["avg_us"], (ts - rf["avg_us"]) / ts * 100))
 print("  traced run, bench.py event pairs          : %d launches, average %.2f us -> frac %.3f (under the tracer the start marker queues behind the profiler's packets)" % (ep["launches"], ep["avg_us"], ep["frac"]))
 p = plain["roofline"]
 print("  untraced run (%s), in-kernel window: %d launches, average %.2f us -> frac %.3f (median %.2f us, fastest %.2f us)  <- the reported figure: first workgroup in -> last wave out on the device wall clock (the same clock under the tracer: %.2f us)" % (sys.argv[3].split("/")[-1], p["launches"], p["avg_us"], p["frac"], p["median_us"], p["min_us"], rf["avg_us"]))
