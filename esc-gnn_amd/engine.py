@@ -348,6 +348,9 @@ class _NodeCache(object):
         self.counters = [m.num_batches_tracked for m in model.modules()
                          if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None]
         self.bns = [m for m in model.modules() if hasattr(m, "sync_group")]     # see _bns
+        with torch.enable_grad():       # the AccumulateGrad node of the first parameter: _node_backward asks the engine about it
+            p0 = self.params[0]
+            self.acc0 = p0.view_as(p0).grad_fn.next_functions[0][0] if p0.requires_grad else None
         index = {id(p): i for i, p in enumerate(self.params)}
         describe_fn = getattr(self, "_describe", describe)
         self.template = describe_fn(model, lambda p: self.MARK + index[id(p)])
@@ -404,8 +407,22 @@ class _NodeCache(object):
         through autograd).  When a FlatAdam / FlatBucket owns every .grad, only the FIRST parameter: the backward writes
         (clean bucket) or adds (otherwise) the gradients into the bucket itself and returns none, so the graph carries one
         edge instead of one AccumulateGrad per parameter — 104 of them cost the reference's loop ~0.25 ms of host time per
-        step (tools/measure/dropin_prof.py).  torch.autograd.grad(loss, parameters) does not see such a node's gradients."""
+        step (tools/measure/dropin_prof.py).  torch.autograd.grad through such a node reaches its one input only."""
         return (self.params[0],) if self.owning_bucket() is not None else tuple(self.params)
+
+
+def _under_autograd_grad(cache):
+    """inside a backward: is this torch.autograd.grad (functional: nothing may be accumulated) rather than .backward()?  The autograd
+    engine refuses the question about a leaf's AccumulateGrad node exactly in that case."""
+    if cache.acc0 is None:
+        return False
+    try:
+        torch._C._will_engine_execute_node(cache.acc0)
+        return False
+    except RuntimeError as exc:
+        return "autograd.grad" in str(exc)
+    except Exception:
+        return False
 
 
 def _node_backward(ctx, dpred, entry):
@@ -419,6 +436,17 @@ def _node_backward(ctx, dpred, entry):
     g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
     slim = ctx.n_in < len(cache.params)
     none = (None, None, None) + (None,) * ctx.n_in
+    if _under_autograd_grad(cache):
+        # torch.autograd.grad(...): a functional call — no .grad may change.  The gradients of the node's inputs are returned (all
+        # parameters, or the one a short-form node was built on; asking for another parameter of such a node is autograd's own
+        # "not used in the graph" error)
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dpred.device)
+        desc = cache.descriptor(flat.data_ptr())
+        nv.call(entry, ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())
+        ctx.ws = ctx.keep = None
+        grads = tuple(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None
+                      for p, o in zip(cache.params[:ctx.n_in], cache.offsets[:ctx.n_in]))
+        return (None, None, None) + grads
 
     def run(desc):
         nv.call(entry, ctypes.byref(desc), ctypes.byref(ctx.b), ctx.ws.data_ptr(), g.data_ptr(), nv.stream())

@@ -579,6 +579,8 @@ def test_engine_node_writes_into_a_clean_flatadam_bucket():
             p.grad = None
         loss_of(m1, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
         want = {n: p.grad.clone() for n, p in m1.named_parameters()}
+        if not extra:
+            want_plain = want
         opt = E.optim.FlatAdam(m2.parameters(), lr=1e-3) if not extra else opt      # noqa: F821  (same bucket both rounds)
         opt.zero_grad()
         loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
@@ -605,6 +607,20 @@ def test_engine_node_writes_into_a_clean_flatadam_bucket():
         loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), extra).backward()
         for n, p in m2.named_parameters():
             _close(p.grad, want[n].cpu(), "re-bound grad " + n, tol=2e-5)
+    # torch.autograd.grad through the node is functional: the requested gradients come back, the bucket stays untouched
+    opt.engine_direct = False                 # (all parameters are inputs of the node: every gradient can be asked for)
+    opt.zero_grad()
+    before = opt.flat_grad.clone()
+    got = torch.autograd.grad(loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), False), list(m2.parameters()))
+    assert torch.equal(opt.flat_grad, before)
+    for (n, _), g in zip(m2.named_parameters(), got):
+        _close(g, want_plain[n].cpu(), "autograd.grad " + n, tol=2e-5)
+    opt.engine_direct = True
+    opt.zero_grad()
+    p0 = next(iter(m2.parameters()))
+    (g0,) = torch.autograd.grad(loss_of(m2, E.Data(**{k: v.clone() for k, v in bt.items()}), False), [p0])     # short-form node: its one input
+    assert torch.equal(opt.flat_grad, before)
+    _close(g0, want_plain[next(iter(dict(m2.named_parameters())))].cpu(), "autograd.grad of the short form's input", tol=2e-5)
     # with a bucket that owns every .grad the node takes ONE parameter as its differentiable input (no AccumulateGrad edge per
     # parameter); without one, all of them
     opt.zero_grad()
