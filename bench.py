@@ -188,7 +188,10 @@ def main():
     # dominant-kernel timing with HIP events on the launch stream, inside the timed region
     nv.prof_reset("agg_fwd")
     # + the kernel's own first-wave-in -> last-wave-out window, stamped by the launches of the first 10 timed steps
-    nv.prof_span_arm("agg_fwd", min(args.steps, 10) * max(args.layers - 1, 1))
+    try:
+        nv.prof_span_arm("agg_fwd", min(args.steps, 10) * max(args.layers - 1, 1))
+    except Exception as exc:                                    # the roofline then falls back to the event pairs (clock says so)
+        print("bench: in-kernel stamps unavailable (%s)" % exc, file=sys.stderr)
     nv.prof_enable("agg_fwd", True)
     torch.cuda.synchronize()
     if world > 1:
@@ -203,7 +206,10 @@ def main():
     nv.prof_enable("agg_fwd", False)
     n_agg, ms_agg = nv.prof_read("agg_fwd")
     agg_launch_ms = nv.prof_read_all("agg_fwd")
-    agg_span_us = [u for u in nv.prof_span_read("agg_fwd") if u > 0]
+    try:
+        agg_span_us = [u for u in nv.prof_span_read("agg_fwd") if 0 < u < 1e4]      # (a wrapped / unset stamp is dropped)
+    except Exception:
+        agg_span_us = []
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
